@@ -1,0 +1,153 @@
+/*
+ * vlg_hip.h - C ABI of libvlg_hip.so, the MI355X (gfx950) kernels behind the
+ * per-clip layout-generation training step.
+ *
+ * The reference (gongaa/video-layout-generation) has no native code and no FFI:
+ * every device op is a stock torch.nn call made from src/trainer.py.  Each entry
+ * point below therefore cites the torch call site in the reference it replaces
+ * (file:line under /root/reference), or says SELF-ORACLE where BASELINE.json
+ * names an op the reference does not contain.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless
+ *     the name ends in _host; the caller (PyTorch) owns every buffer
+ *   - `stream` is a hipStream_t passed as void*; kernels are stream-ordered on it,
+ *     never allocate, never synchronise, keep no global state
+ *   - return value: 0 on success, otherwise a hipError_t (launch/config error) or
+ *     VLG_ERR_* below; the Python side raises RuntimeError on non-zero
+ *   - token-major activations use the INTERNAL row order  m = (b*N + n)*T + t
+ *     (all frames of one slot contiguous: one T x d tile per (clip, slot));
+ *     inputs/targets keep the public (B,T,N) order and are re-indexed in-kernel
+ */
+#ifndef VLG_HIP_H
+#define VLG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLG_ERR_SHAPE   1001   /* unsupported or inconsistent shape argument */
+#define VLG_ERR_ALIGN   1002   /* pointer or leading dimension not 16-byte aligned */
+
+/* library / build identification */
+int         vlg_abi_version(void);
+const char* vlg_build_arch(void);          /* "gfx950" */
+
+/* ------------------------------------------------------------------ embedding
+ * Object-slot embedding.  SELF-ORACLE; lookup semantics = nn.Embedding row gather
+ * (reference src/models/simple.py:23,41).
+ *   x[m,:] = cls_emb[slot_class[b,t,n]] + box_w @ slot_box[b,t,n] + box_b + time_emb[t]
+ * bwd writes per-block partial slabs laid out [cls_emb | box_w | box_b | time_emb]
+ * (the first tensors of the flat gradient buffer); vlg_reduce_slabs sums them. */
+int vlg_embed_fwd(const int64_t* slot_class, const float* slot_box,
+                  const float* cls_emb, const float* box_w, const float* box_b,
+                  const float* time_emb, float* x,
+                  int B, int T, int N, int d, int vocab, void* stream);
+int vlg_embed_bwd_slabs(void);             /* number of slabs vlg_embed_bwd writes */
+int vlg_embed_bwd(const float* dx, const int64_t* slot_class, const float* slot_box,
+                  float* slabs, int64_t slab_stride,
+                  int B, int T, int N, int d, int vocab, void* stream);
+
+/* ------------------------------------------------------------------ layer-norm
+ * SELF-ORACLE (F.layer_norm arithmetic, biased variance, eps inside the sqrt).
+ * bwd: dx_out = (dres ? dres : 0) + LN'(dy); partial [dgamma | dbeta] slabs. */
+int vlg_layernorm_fwd(const float* x, const float* gamma, const float* beta,
+                      float* y, float* mean, float* rstd,
+                      int64_t rows, int d, float eps, void* stream);
+int vlg_layernorm_bwd_slabs(int64_t rows);
+int vlg_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                      const float* gamma, const float* dres, float* dx_out,
+                      float* slabs, int64_t slab_stride,
+                      int64_t rows, int d, void* stream);
+
+/* ------------------------------------------------------------------------ GEMM
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs for the dense QKV/FFN/head projections.
+ * SELF-ORACLE (F.linear arithmetic); the reference's dense contraction is conv only.
+ *
+ * vlg_linear_fwd : C[M,N] = A[M,K] . W[N,K]^T + bias      (epilogue selects extras)
+ * vlg_linear_dgrad: C[M,K] = A[M,N] . W[N,K]              (epilogue selects extras)
+ * vlg_linear_wgrad: slabs[s][N*K + N] = partial ( dY[M,N]^T . X[M,K] | colsum dY )
+ */
+#define VLG_EPI_NONE   0
+#define VLG_EPI_BIAS   1   /* + bias[col]                                            */
+#define VLG_EPI_GELU   2   /* aux_out = pre-activation, C = gelu(pre)   (needs BIAS) */
+#define VLG_EPI_RESID  4   /* C = acc (+bias) + aux_in[row,col]                      */
+#define VLG_EPI_DGELU  8   /* C = acc * gelu'(aux_in[row,col])                       */
+int vlg_linear_fwd(const float* A, int lda, const float* W, int ldw, const float* bias,
+                   float* C, int ldc, const float* aux_in, float* aux_out,
+                   int64_t M, int N, int K, int epilogue, void* stream);
+int vlg_linear_dgrad(const float* dY, int ldy, const float* W, int ldw,
+                     float* dX, int ldx, const float* aux_in,
+                     int64_t M, int N, int K, int epilogue, void* stream);
+int vlg_linear_wgrad_slabs(int64_t M, int N, int K);
+int vlg_linear_wgrad(const float* dY, int ldy, const float* X, int ldx,
+                     float* slabs, int64_t slab_stride,
+                     int64_t M, int N, int K, void* stream);
+
+/* ------------------------------------------------------------------- attention
+ * Temporal encoder core: causal softmax attention along T for each (clip, slot,
+ * head); one wavefront owns one T x 64 tile staged in LDS.  SELF-ORACLE.
+ * qkv is [rows, 3d] = [q | k | v]; head h owns columns h*64..h*64+63 of each. */
+int vlg_attention_fwd(const float* qkv, float* o, int64_t n_seq, int T, int d, void* stream);
+int vlg_attention_bwd(const float* qkv, const float* dout, float* dqkv,
+                      int64_t n_seq, int T, int d, void* stream);
+
+/* ---------------------------------------------------------------------- losses
+ * Fused softmax-cross-entropy + smooth-L1 + IoU, forward and backward in one pass.
+ *   CE    : nn.CrossEntropyLoss(reduction='mean')   reference src/trainer.py:124,250
+ *   weights 40 / 20 / 10                            reference src/trainer.py:248-250
+ *   smooth-L1, IoU : SELF-ORACLE
+ * out/dout are [rows, ld] with columns [0,C) = logits, [C,C+4) = raw box.
+ * loss_out[4] = {total, smooth_l1, iou, ce}.  scratch holds >= vlg_layout_loss_scratch()
+ * floats. */
+int vlg_layout_loss_scratch(void);
+int vlg_layout_loss(const float* out, int ld, const int64_t* tgt_class, const float* tgt_box,
+                    const float* valid, float* dout, float* loss_out, float* scratch,
+                    int B, int T, int N, int n_classes, float beta, float iou_eps,
+                    float w_reg, float w_iou, float w_ce, void* stream);
+
+/* ------------------------------------------------------------------ reductions */
+int vlg_reduce_slabs(const float* slabs, int64_t slab_stride, int n_slabs,
+                     float* dst, int64_t len, void* stream);
+
+/* ------------------------------------------------------------------- optimiser
+ * torch.optim.Adam(lr, betas=(beta1, 0.999)) on one flat fp32 buffer
+ * (reference src/trainer.py:83,258; src/main.py:139-141).  `step` is 1-based.
+ * grad_scale multiplies the gradient first (1/world_size turns an all-reduce SUM
+ * into DDP's mean, reference src/trainer.py:113). */
+int vlg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  int64_t n, int step, float lr, float beta1, float beta2, float eps,
+                  float grad_scale, void* stream);
+
+/* ---------------------------------------------------- reference-real image ops
+ * Pixel-space ops of the reference step that exist verbatim in the reference.
+ *   vlg_ce_nchw        nn.CrossEntropyLoss('mean') on (b,C,H,W) logits / (b,H,W) int64
+ *                      targets; writes loss[0] and dlogits = grad_scale * dCE
+ *                                                     reference src/trainer.py:124,250
+ *   vlg_l1_mean        nn.L1Loss()                    reference src/trainer.py:130,248
+ *   vlg_gradient_loss  GradientLoss.forward           reference src/loss.py:20-25
+ *   vlg_ssim_loss      SsimLoss.SSIM/forward          reference src/loss.py:68-91
+ *   vlg_prep_input     normalise + concat + flip      reference src/trainer.py:193-206
+ * Each loss writes value to loss[0] and, when grad != NULL, d(loss)/d(first arg) *
+ * grad_scale.  scratch >= vlg_image_loss_scratch() floats. */
+int vlg_image_loss_scratch(void);
+int vlg_ce_nchw(const float* logits, const int64_t* target, float* dlogits, float* loss,
+                float* scratch, int b, int C, int64_t hw, float grad_scale, void* stream);
+int vlg_l1_mean(const float* a, const float* b, float* da, float* loss, float* scratch,
+                int64_t n, float grad_scale, void* stream);
+int vlg_gradient_loss(const float* a, const float* b, float* da, float* loss, float* scratch,
+                      int planes, int H, int W, float grad_scale, void* stream);
+int vlg_ssim_loss(const float* x, const float* y, float* dx, float* loss, float* scratch,
+                  int b, int C, int H, int W, float grad_scale, void* stream);
+int vlg_prep_input(const float* e1, const float* seg1, const float* frame1,
+                   const float* frame2, const float* seg2, const float* e2,
+                   const float* frame3, const int64_t* seg3,
+                   float* x10, float* frame3_out, int64_t* seg3_out,
+                   int b, int H, int W, int flip, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLG_HIP_H */

@@ -1,0 +1,264 @@
+"""GPU parity tests, one op at a time, through the C ABI (ctypes -> libvlg_hip.so).
+
+Checker: oracle/layout_spec.py (torch-CPU arithmetic + autograd).  The layout-token ops have
+no reference counterpart, so these are SELF-ORACLE parity tests; the
+tolerance is BASELINE.json's 1e-4 (fp32) unless a test states otherwise.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+from oracle import layout_spec as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from vlg import hip
+    hip.load()
+    return hip
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def reduce_slabs(H, slabs, stride, n, length, dev):
+    dst = torch.empty(length, device=dev)
+    H.call("vlg_reduce_slabs", slabs.data_ptr(), stride, n, dst.data_ptr(), length, stream())
+    return dst
+
+
+# ------------------------------------------------------------------------ embedding
+@pytest.mark.parametrize("B,T,N,d", [(2, 4, 8, 64), (3, 16, 5, 256), (2, 32, 4, 512)])
+def test_embed_fwd_bwd(H, dev, B, T, N, d):
+    torch.manual_seed(0)
+    vocab = 21
+    p = {"cls_emb": torch.randn(vocab, d), "box_w": torch.randn(d, 4) * 0.5, "box_b": torch.randn(d) * 0.1,
+         "time_emb": torch.randn(T, d)}
+    cls = torch.randint(0, vocab, (B, T, N))
+    box = torch.rand(B, T, N, 4)
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    want = O.embed(q, cls, box)                                  # (B,T,N,d)
+    gy = torch.randn(B, T, N, d)
+    want.backward(gy)
+    pd = {k: v.to(dev) for k, v in p.items()}
+    x = torch.empty(B * N * T, d, device=dev)
+    H.call("vlg_embed_fwd", cls.to(dev).data_ptr(), box.to(dev).data_ptr(), pd["cls_emb"].data_ptr(),
+           pd["box_w"].data_ptr(), pd["box_b"].data_ptr(), pd["time_emb"].data_ptr(), x.data_ptr(),
+           B, T, N, d, vocab, stream())
+    got = x.view(B, N, T, d).permute(0, 2, 1, 3)
+    assert_close(got, want, what="embed fwd")
+    # backward
+    dx = gy.permute(0, 2, 1, 3).contiguous().view(B * N * T, d).to(dev)
+    L = vocab * d + d * 4 + d + T * d
+    ns = H.load().vlg_embed_bwd_slabs()
+    slabs = torch.empty(ns * L, device=dev)
+    clsd, boxd = cls.to(dev), box.to(dev)
+    H.call("vlg_embed_bwd", dx.data_ptr(), clsd.data_ptr(), boxd.data_ptr(), slabs.data_ptr(), L, B, T, N, d, vocab,
+           stream())
+    g = reduce_slabs(H, slabs, L, ns, L, dev)
+    o = 0
+    for name, n in (("cls_emb", vocab * d), ("box_w", d * 4), ("box_b", d), ("time_emb", T * d)):
+        assert_close(g[o:o + n].view(p[name].shape), q[name].grad, rtol=1e-4, atol=1e-4, what="embed d" + name)
+        o += n
+
+
+# ----------------------------------------------------------------------- layer-norm
+@pytest.mark.parametrize("rows,d", [(7, 64), (1000, 256), (513, 512), (64, 128), (40, 1024)])
+def test_layernorm_fwd_bwd(H, dev, rows, d):
+    torch.manual_seed(1)
+    x = (torch.randn(rows, d) * 2 + 0.5).requires_grad_(True)
+    g = (torch.rand(d) + 0.5).requires_grad_(True)
+    b = torch.randn(d).requires_grad_(True)
+    y = F.layer_norm(x, (d,), g, b, 1e-5)
+    dy = torch.randn(rows, d)
+    y.backward(dy)
+    xd, gd, bd = x.detach().to(dev), g.detach().to(dev), b.detach().to(dev)
+    yd = torch.empty(rows, d, device=dev)
+    mean = torch.empty(rows, device=dev)
+    rstd = torch.empty(rows, device=dev)
+    H.call("vlg_layernorm_fwd", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), yd.data_ptr(), mean.data_ptr(),
+           rstd.data_ptr(), rows, d, 1e-5, stream())
+    assert_close(yd, y, what="ln fwd")
+    assert_close(mean, x.detach().mean(-1), what="ln mean")
+    ns = H.load().vlg_layernorm_bwd_slabs(rows)
+    slabs = torch.empty(ns * 2 * d, device=dev)
+    res = torch.randn(rows, d)
+    dres = res.to(dev)
+    dyd = dy.to(dev)
+    H.call("vlg_layernorm_bwd", dyd.data_ptr(), xd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
+           dres.data_ptr(), dres.data_ptr(), slabs.data_ptr(), 2 * d, rows, d, stream())      # in place
+    assert_close(dres, res + x.grad, rtol=1e-4, atol=2e-5, what="ln dx (+residual, in place)")
+    gb = reduce_slabs(H, slabs, 2 * d, ns, 2 * d, dev)
+    assert_close(gb[:d], g.grad, rtol=1e-4, atol=1e-4, what="ln dgamma")
+    assert_close(gb[d:], b.grad, rtol=1e-4, atol=1e-4, what="ln dbeta")
+    # without residual
+    dx2 = torch.empty(rows, d, device=dev)
+    H.call("vlg_layernorm_bwd", dyd.data_ptr(), xd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
+           0, dx2.data_ptr(), slabs.data_ptr(), 2 * d, rows, d, stream())
+    assert_close(dx2, x.grad, rtol=1e-4, atol=2e-5, what="ln dx")
+
+
+# ----------------------------------------------------------------------------- GEMM
+def _exact_gelu(u):
+    return F.gelu(u)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 768, 256), (384, 256, 1024), (128, 64, 64), (1000, 24, 256)])
+def test_linear_fwd_bias(H, dev, M, N, K):
+    torch.manual_seed(2)
+    a, w, b = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+    want = F.linear(a.double(), w.double(), b.double()).float()
+    ad, wd, bd = a.to(dev), w.to(dev), b.to(dev)
+    c = torch.full((M, N), float("nan"), device=dev)
+    H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, 0, M, N, K,
+           H.EPI_BIAS, stream())
+    assert_close(c, want, rtol=1e-4, atol=1e-5, what="linear fwd bias")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 1024, 256)])
+def test_linear_fwd_gelu_and_resid(H, dev, M, N, K):
+    torch.manual_seed(3)
+    a, w, b, r = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N), torch.randn(M, N)
+    pre = F.linear(a.double(), w.double(), b.double())
+    ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    c = torch.empty(M, N, device=dev)
+    u = torch.empty(M, N, device=dev)
+    H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, u.data_ptr(),
+           M, N, K, H.EPI_BIAS | H.EPI_GELU, stream())
+    assert_close(u, pre.float(), what="ffn pre-activation")
+    assert_close(c, F.gelu(pre).float(), what="ffn gelu")
+    H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, rd.data_ptr(), 0,
+           M, N, K, H.EPI_BIAS | H.EPI_RESID, stream())
+    assert_close(c, (pre + r.double()).float(), what="linear + residual")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 768, 256), (200, 256, 1024), (384, 1024, 256), (500, 24, 256), (128, 64, 64)])
+def test_linear_dgrad_wgrad(H, dev, M, N, K):
+    torch.manual_seed(4)
+    dy, w, x = torch.randn(M, N), torch.randn(N, K) / math.sqrt(N), torch.randn(M, K)
+    dyd, wd, xd = dy.to(dev), w.to(dev), x.to(dev)
+    dx = torch.empty(M, K, device=dev)
+    H.call("vlg_linear_dgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, 0, M, N, K, H.EPI_NONE, stream())
+    assert_close(dx, (dy.double() @ w.double()).float(), rtol=1e-4, atol=1e-5, what="dgrad")
+    u = torch.randn(M, K)
+    ud = u.to(dev)
+    H.call("vlg_linear_dgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, ud.data_ptr(), M, N, K,
+           H.EPI_DGELU, stream())
+    uu = u.double().requires_grad_(True)
+    F.gelu(uu).backward(dy.double() @ w.double())
+    assert_close(dx, uu.grad.float(), rtol=1e-4, atol=1e-5, what="dgrad * gelu'")
+    ns = H.load().vlg_linear_wgrad_slabs(M, N, K)
+    stride = N * K + N
+    slabs = torch.full((ns * stride,), float("nan"), device=dev)
+    H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, M, N, K, stream())
+    g = reduce_slabs(H, slabs, stride, ns, stride, dev)
+    sc = math.sqrt(M)
+    assert_close(g[:N * K].view(N, K) / sc, (dy.double().t() @ x.double()).float() / sc, rtol=1e-4, atol=1e-5, what="wgrad")
+    assert_close(g[N * K:] / sc, dy.double().sum(0).float() / sc, rtol=1e-4, atol=1e-5, what="bias grad")
+
+
+# ------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("T,d,n_seq", [(4, 64, 5), (8, 128, 3), (16, 256, 6), (32, 256, 3), (16, 512, 2)])
+def test_attention_fwd_bwd(H, dev, T, d, n_seq):
+    torch.manual_seed(5)
+    Hn = d // 64
+    qkv = torch.randn(1, T, n_seq, 3 * d, requires_grad=True)        # (B=1,T,N=n_seq,3d)
+    want = O.temporal_attention(qkv, Hn)                              # (1,T,n_seq,d)
+    do = torch.randn(1, T, n_seq, d)
+    want.backward(do)
+    to_int = lambda t: t[0].permute(1, 0, 2).contiguous().view(n_seq * T, -1)
+    qd = to_int(qkv.detach()).to(dev)
+    o = torch.full((n_seq * T, d), float("nan"), device=dev)
+    H.call("vlg_attention_fwd", qd.data_ptr(), o.data_ptr(), n_seq, T, d, stream())
+    assert_close(o, to_int(want.detach()), what="attention fwd")
+    dod = to_int(do).to(dev)
+    dq = torch.full((n_seq * T, 3 * d), float("nan"), device=dev)
+    H.call("vlg_attention_bwd", qd.data_ptr(), dod.data_ptr(), dq.data_ptr(), n_seq, T, d, stream())
+    assert_close(dq, to_int(qkv.grad), rtol=1e-4, atol=2e-5, what="attention bwd")
+
+
+# ----------------------------------------------------------------------------- loss
+@pytest.mark.parametrize("B,T,N,var", [(2, 4, 8, False), (3, 16, 7, True), (4, 8, 33, True)])
+def test_layout_loss(H, dev, B, T, N, var):
+    torch.manual_seed(6)
+    batch = O.synthetic_batch(B, T, N, seed=6, variable_n=var, min_valid=2)
+    logits = (torch.randn(B, T, N, 20) * 2).requires_grad_(True)
+    raw = torch.randn(B, T, N, 4).requires_grad_(True)
+    parts = O.losses(logits, raw, batch["tgt_class"], batch["tgt_box"], batch["valid"])
+    parts[0].backward()
+    M = B * T * N
+    to_int = lambda t: t.permute(0, 2, 1, 3).contiguous().view(M, -1)
+    out = torch.cat([to_int(logits.detach()), to_int(raw.detach())], dim=1).contiguous().to(dev)
+    dout = torch.full((M, 24), float("nan"), device=dev)
+    loss = torch.zeros(4, device=dev)
+    scratch = torch.zeros(H.load().vlg_layout_loss_scratch(), device=dev)
+    tc, tb, va = batch["tgt_class"].to(dev), batch["tgt_box"].to(dev), batch["valid"].to(dev)
+    H.call("vlg_layout_loss", out.data_ptr(), 24, tc.data_ptr(), tb.data_ptr(), va.data_ptr(), dout.data_ptr(),
+           loss.data_ptr(), scratch.data_ptr(), B, T, N, 20, O.SMOOTH_L1_BETA, O.IOU_EPS, O.W_REG, O.W_IOU, O.W_CE,
+           stream())
+    assert_close(loss, torch.stack([x.detach() for x in parts]), rtol=1e-4, atol=1e-6, what="loss values")
+    want = torch.cat([to_int(logits.grad), to_int(raw.grad)], dim=1)
+    assert_close(dout, want, rtol=1e-4, atol=1e-7, what="loss grads")
+
+
+def test_layout_loss_all_masked(H, dev):
+    """Edge case: no valid slot at all -> losses 0, gradients 0 (count clamps to 1)."""
+    B, T, N, M = 1, 4, 4, 16
+    out = torch.randn(M, 24, device=dev)
+    dout = torch.full((M, 24), float("nan"), device=dev)
+    loss = torch.ones(4, device=dev)
+    scratch = torch.zeros(H.load().vlg_layout_loss_scratch(), device=dev)
+    tc = torch.zeros(B, T, N, dtype=torch.int64, device=dev)
+    tb = torch.rand(B, T, N, 4, device=dev)
+    va = torch.zeros(B, T, N, device=dev)
+    H.call("vlg_layout_loss", out.data_ptr(), 24, tc.data_ptr(), tb.data_ptr(), va.data_ptr(), dout.data_ptr(),
+           loss.data_ptr(), scratch.data_ptr(), B, T, N, 20, 0.1, 1e-7, 40.0, 20.0, 10.0, stream())
+    assert float(loss.abs().max()) == 0.0
+    assert float(dout.abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------- reduce and Adam
+def test_reduce_slabs(H, dev):
+    torch.manual_seed(7)
+    for n, L, stride in ((1, 8, 8), (7, 1000, 1024), (41, 4096, 4096)):
+        s = torch.randn(n, stride)
+        got = reduce_slabs(H, s.to(dev).flatten(), stride, n, L, dev)
+        assert_close(got, s[:, :L].double().sum(0).float(), rtol=1e-5, atol=1e-5, what="reduce_slabs")
+
+
+def test_adam_matches_torch_optim(H, dev):
+    """Three Adam(beta1=0.5) steps from a fixed state vs torch.optim.Adam (reference src/trainer.py:83)."""
+    torch.manual_seed(8)
+    n = 4096 + 8
+    p0 = torch.randn(n)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-4, betas=(0.5, 0.999))
+    p = p0.to(dev)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        g = torch.randn(n) * (10.0 ** (step - 2))
+        ref.grad = g.clone()
+        opt.step()
+        gd = (g * 4).to(dev)            # grad_scale 0.25 undoes the x4: models all-reduce SUM over 4 ranks
+        H.call("vlg_adam_step", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, step, 2e-4, 0.5, 0.999,
+               1e-8, 0.25, stream())
+        assert_close(p, ref.detach(), rtol=1e-6, atol=1e-7, what="adam step %d" % step)
+
+
+def test_bad_arguments_raise(H, dev):
+    x = torch.zeros(64, 64, device=dev)
+    with pytest.raises(H.HipError):
+        H.call("vlg_attention_fwd", x.data_ptr(), x.data_ptr(), 1, 5, 64, stream())          # T not supported
+    with pytest.raises(H.HipError):
+        H.call("vlg_layernorm_fwd", x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+               x.data_ptr(), 64, 100, 1e-5, stream())                                            # d not supported
+    with pytest.raises(H.HipError):
+        H.call("vlg_linear_fwd", x.data_ptr() + 4, 64, x.data_ptr(), 64, x.data_ptr(), x.data_ptr(), 64, 0, 0,
+               8, 64, 64, H.EPI_BIAS, stream())                                                  # misaligned A

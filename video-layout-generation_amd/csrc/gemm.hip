@@ -1,0 +1,315 @@
+// fp32 MFMA GEMMs for the dense QKV / FFN / head projections (MFMA-bound in fp32).
+//
+// One kernel template serves forward (A.W^T), data-gradient (dY.W) and weight-gradient
+// (dY^T.X, split over the token dimension) by choosing how each operand tile sits in LDS:
+//   *_KC  tile[row][k]  - operand rows are contraction-contiguous in memory; row stride 36
+//                         floats, so the per-lane float4 fragment reads (ds_read_b128) are
+//                         bank-conflict-free (36*i mod 64 hits 16 distinct 4-bank slots)
+//   *_MC  tile[k][row]  - operand is contraction-major in memory (W for dgrad, dY and X for
+//                         wgrad); fragments are 4 ds_read_b32, lanes 0..31 on consecutive banks
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles/SIMD, 157 TFLOP/s chip peak).  Its two
+// k-slices per instruction go to lane halves h = lane>>5; we assign k = 8*s + 4*h + j to
+// MFMA j of chunk s so ONE float4 read feeds four MFMAs (A and B use the same assignment,
+// the contraction order inside a chunk is free).
+// Block = 256 threads = 4 waves; 128x128 tile => each wave owns 64x64 = 2x2 MFMA tiles
+// (64 accumulator VGPRs).  BK = 32, register-staged double buffering (global loads for tile
+// k+1 are issued before the MFMAs of tile k, written to the other LDS buffer after them, one
+// barrier per tile).  73.7 KB LDS per block -> 2 blocks / CU, so one block's MFMAs cover the
+// other's staging.  blockIdx is remapped so tiles that share an A panel sit on one XCD (L2).
+// Algorithmic work per launch: 2*M*N*K flop; bytes 4*(M*K + N*K + M*N) (+ aux operands).
+#include "common.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GEMM_BK 32
+#define GEMM_LDK 36          // padded row stride of a *_KC tile
+#define GEMM_THREADS 256
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* aux_in; float* aux_out;
+    int64_t M;               // rows of C (non-contraction extent of A)
+    int N;                   // cols of C (non-contraction extent of B)
+    int64_t Kc;              // contraction extent
+    int lda, ldb, ldc;
+    int tiles_m, tiles_n, splits;
+    int64_t kc_per_split, slab_stride, colsum_off;
+};
+
+template <int BR, bool KC>
+struct Tile {
+    static constexpr int NV = BR / 32;                       // float4 per thread per tile
+    static constexpr int FLOATS = KC ? BR * GEMM_LDK : GEMM_BK * BR;
+
+    __device__ static __forceinline__ void gload(float4 (&r)[NV], const float* __restrict__ P, int ld,
+                                                 int64_t r0, int64_t R, int64_t k0, int64_t kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if constexpr (KC) {
+                const int64_t gr = r0 + (tid >> 3) + 32 * i;
+                const int64_t gk = k0 + ((tid & 7) << 2);
+                r[i] = (gr < R && gk < kend) ? ld4(P + gr * ld + gk) : f4_zero();
+            } else {
+                const int idx = tid + GEMM_THREADS * i;
+                const int64_t gk = k0 + idx / (BR / 4);
+                const int64_t gc = r0 + ((idx % (BR / 4)) << 2);
+                r[i] = (gk < kend && gc < R) ? ld4(P + gk * ld + gc) : f4_zero();
+            }
+        }
+    }
+    __device__ static __forceinline__ void sstore(const float4 (&r)[NV], float* S, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if constexpr (KC) st4(S + ((tid >> 3) + 32 * i) * GEMM_LDK + ((tid & 7) << 2), r[i]);
+            else st4(S + ((tid + GEMM_THREADS * i) << 2), r[i]);
+        }
+    }
+    // 4 fragment values of tile row `row` for chunk s, lane half h:  k = 8s + 4h + j
+    __device__ static __forceinline__ void frag(float (&f)[4], const float* S, int row, int s, int h) {
+        if constexpr (KC) {
+            const float4 t = ld4(S + row * GEMM_LDK + 8 * s + 4 * h);
+            f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = S[(8 * s + 4 * h + j) * BR + row];
+        }
+    }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int WM = (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 4 : 1);
+    constexpr int WN = 4 / WM;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    using TA = Tile<BM, A_KC>;
+    using TB = Tile<BN, B_KC>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::FLOATS + TB::FLOATS)];
+    float* const As0 = smem;                       // As[buf] = As0 + buf * TA::FLOATS
+    float* const Bs0 = smem + 2 * TA::FLOATS;      // Bs[buf] = Bs0 + buf * TB::FLOATS
+
+    // XCD-aware remap: hardware deals blocks round-robin over 8 XCDs; give each XCD a
+    // contiguous run of logical tiles (bijective for any grid size)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int split = swz / ntile;
+    const int tile = swz - split * ntile;
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const int64_t kbeg = (int64_t)split * g.kc_per_split;
+    int64_t kend = kbeg + g.kc_per_split;
+    if (kend > g.Kc) kend = g.Kc;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float colacc = 0.f;
+    // bias is fetched before the main loop so no load is pending in the store epilogue
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        bv[j] = 0.f;
+        if constexpr ((EPI & VLG_EPI_BIAS) != 0) {
+            const int col = n0 + (wn * TN + j) * 32 + l31;
+            bv[j] = g.bias[col < g.N ? col : g.N - 1];
+        }
+    }
+
+    float4 ra[TA::NV], rb[TB::NV];
+    const int nk = (int)((kend - kbeg + GEMM_BK - 1) / GEMM_BK);
+    if (nk > 0) {
+        TA::gload(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid);
+        TB::gload(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+        TA::sstore(ra, As0, tid);
+        TB::sstore(rb, Bs0, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int64_t k0 = kbeg + (int64_t)(kt + 1) * GEMM_BK;
+            TA::gload(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
+            TB::gload(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+        }
+        const float* as = As0 + cur * TA::FLOATS;
+        const float* bs = Bs0 + cur * TB::FLOATS;
+#pragma unroll
+        for (int s = 0; s < GEMM_BK / 8; ++s) {
+            float a[TM][4], b[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) TA::frag(a[i], as, (wm * TM + i) * 32 + l31, s, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) TB::frag(b[j], bs, (wn * TN + j) * 32 + l31, s, h);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (COLSUM) {
+            // bias gradient: column sums of the dY tile, taken once per row-tile (tn == 0)
+            if (tn == 0 && tid < BM) {
+#pragma unroll 8
+                for (int kk = 0; kk < GEMM_BK; ++kk) colacc += as[kk * BM + tid];
+            }
+        }
+        if (more) {
+            TA::sstore(ra, As0 + (cur ^ 1) * TA::FLOATS, tid);
+            TB::sstore(rb, Bs0 + (cur ^ 1) * TB::FLOATS, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h.
+    // 32 lanes of a half write one 128-B row segment per store.
+    float* Cs = g.C + (int64_t)split * g.slab_stride;
+    const int64_t row0 = m0 + wm * TM * 32 + 4 * h;
+    const int col0 = n0 + wn * TN * 32 + l31;
+    const int64_t base = row0 * g.ldc + col0;
+    const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    auto emit = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (GUARD && col0 + j * 32 >= g.N) continue;
+                float aux[16];
+                if constexpr ((EPI & (VLG_EPI_RESID | VLG_EPI_DGELU)) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                        aux[r] = (!GUARD || row0 + ro < g.M) ? g.aux_in[base + ro * g.ldc + j * 32] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (GUARD && row0 + ro >= g.M) continue;
+                    const int64_t o = base + ro * g.ldc + j * 32;
+                    float v = acc[i][j][r] + bv[j];
+                    if constexpr ((EPI & VLG_EPI_GELU) != 0) { g.aux_out[o] = v; v = gelu_f(v); }
+                    if constexpr ((EPI & VLG_EPI_RESID) != 0) v += aux[r];
+                    if constexpr ((EPI & VLG_EPI_DGELU) != 0) v *= dgelu_f(aux[r]);
+                    Cs[o] = v;
+                }
+            }
+    };
+    if (full) emit(std::false_type{});
+    else emit(std::true_type{});
+    if constexpr (COLSUM) {
+        if (tn == 0 && tid < BM && m0 + tid < g.M) Cs[g.colsum_off + m0 + tid] = colacc;
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
+static int launch_gemm(GemmArgs g, hipStream_t s) {
+    g.tiles_m = (int)((g.M + BM - 1) / BM);
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+    if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
+    auto kern = gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, s, g);
+    return vlg_last_error();
+}
+
+static bool gemm_ptr_ok(const void* p, int ld) { return vlg_aligned16(p) && (ld & 3) == 0; }
+
+extern "C" int vlg_linear_fwd(const float* A, int lda, const float* W, int ldw, const float* bias,
+                              float* C, int ldc, const float* aux_in, float* aux_out,
+                              int64_t M, int N, int K, int epilogue, void* stream) {
+    if (M < 1 || N < 1 || K < 4 || (K & 3) || lda < K || ldw < K || ldc < N) return VLG_ERR_SHAPE;
+    if (!gemm_ptr_ok(A, lda) || !gemm_ptr_ok(W, ldw) || !C) return VLG_ERR_ALIGN;
+    GemmArgs g{};
+    g.A = A; g.B = W; g.C = C; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out;
+    g.M = M; g.N = N; g.Kc = K; g.lda = lda; g.ldb = ldw; g.ldc = ldc;
+    g.splits = 1; g.kc_per_split = K; g.slab_stride = 0; g.colsum_off = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if ((epilogue & VLG_EPI_BIAS) && !bias) return VLG_ERR_SHAPE;
+    if ((epilogue & (VLG_EPI_RESID | VLG_EPI_DGELU)) && !aux_in) return VLG_ERR_SHAPE;
+    if ((epilogue & VLG_EPI_GELU) && !aux_out) return VLG_ERR_SHAPE;
+    const bool narrow = N <= 32;
+    switch (epilogue) {
+        case VLG_EPI_BIAS:
+            return narrow ? launch_gemm<128, 32, true, true, VLG_EPI_BIAS, false>(g, s)
+                          : launch_gemm<128, 128, true, true, VLG_EPI_BIAS, false>(g, s);
+        case VLG_EPI_BIAS | VLG_EPI_GELU:
+            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false>(g, s);
+        case VLG_EPI_BIAS | VLG_EPI_RESID:
+            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false>(g, s);
+        default:
+            return VLG_ERR_SHAPE;
+    }
+}
+
+extern "C" int vlg_linear_dgrad(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx,
+                                const float* aux_in, int64_t M, int N, int K, int epilogue, void* stream) {
+    // dX[M,K] = dY[M,N] . W[N,K]  : contraction over N, W is contraction-major
+    if (M < 1 || N < 4 || (N & 3) || K < 4 || (K & 3) || ldy < N || ldw < K || ldx < K) return VLG_ERR_SHAPE;
+    if (!gemm_ptr_ok(dY, ldy) || !gemm_ptr_ok(W, ldw) || !dX) return VLG_ERR_ALIGN;
+    GemmArgs g{};
+    g.A = dY; g.B = W; g.C = dX; g.aux_in = aux_in;
+    g.M = M; g.N = K; g.Kc = N; g.lda = ldy; g.ldb = ldw; g.ldc = ldx;
+    g.splits = 1; g.kc_per_split = N;
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case VLG_EPI_NONE:
+            return launch_gemm<128, 128, true, false, VLG_EPI_NONE, false>(g, s);
+        case VLG_EPI_DGELU:
+            if (!aux_in) return VLG_ERR_SHAPE;
+            return launch_gemm<128, 128, true, false, VLG_EPI_DGELU, false>(g, s);
+        default:
+            return VLG_ERR_SHAPE;
+    }
+}
+
+// split plan for the weight gradient: enough blocks to fill 256 CUs x 2 blocks, each split a
+// multiple of BK token rows
+static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per) {
+    const int bm = N <= 32 ? 32 : 128;
+    const int64_t tiles = ((N + bm - 1) / bm) * (int64_t)((K + 127) / 128);
+    int64_t want = (512 + tiles - 1) / tiles;
+    const int64_t max_splits = (M + 255) / 256;
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    int64_t p = (M + want - 1) / want;
+    p = (p + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    *per = p;
+    *splits = (int)((M + p - 1) / p);
+}
+
+extern "C" int vlg_linear_wgrad_slabs(int64_t M, int N, int K) {
+    int splits; int64_t per;
+    wgrad_plan(M, N, K, &splits, &per);
+    return splits;
+}
+
+extern "C" int vlg_linear_wgrad(const float* dY, int ldy, const float* X, int ldx, float* slabs,
+                                int64_t slab_stride, int64_t M, int N, int K, void* stream) {
+    // slab[s][n*K + k] = sum_{m in split s} dY[m,n] X[m,k] ;  slab[s][N*K + n] = sum_m dY[m,n]
+    if (M < 1 || N < 4 || (N & 3) || K < 4 || (K & 3) || ldy < N || ldx < K) return VLG_ERR_SHAPE;
+    if (slab_stride < (int64_t)N * K + N) return VLG_ERR_SHAPE;
+    if (!gemm_ptr_ok(dY, ldy) || !gemm_ptr_ok(X, ldx) || !slabs) return VLG_ERR_ALIGN;
+    GemmArgs g{};
+    g.A = dY; g.B = X; g.C = slabs;
+    g.M = N; g.N = K; g.Kc = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
+    wgrad_plan(M, N, K, &g.splits, &g.kc_per_split);
+    g.slab_stride = slab_stride; g.colsum_off = (int64_t)N * K;
+    hipStream_t s = (hipStream_t)stream;
+    return N <= 32 ? launch_gemm<32, 128, false, false, VLG_EPI_NONE, true>(g, s)
+                   : launch_gemm<128, 128, false, false, VLG_EPI_NONE, true>(g, s);
+}

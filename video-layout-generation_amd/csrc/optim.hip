@@ -1,0 +1,82 @@
+// Slab reduction and fused Adam on the flat parameter buffer (both HBM-bound, float4 streams).
+//
+// vlg_reduce_slabs : dst[e] = sum_s slabs[s*stride + e].  Every partial-sum producer in this
+//                    library (weight gradients split over tokens, layer-norm gain/bias sums,
+//                    embedding-table sums) writes slabs and leaves the final sum to this kernel,
+//                    so gradients are bitwise reproducible run to run (no float atomics).
+//                    Algorithmic bytes: 4*len*(n_slabs + 1).
+// vlg_adam_step    : torch.optim.Adam arithmetic on ONE flat fp32 buffer holding every
+//                    parameter (reference src/trainer.py:83,258 - Adam(lr, betas=(beta1,0.999)),
+//                    no weight decay, no amsgrad).  One launch per step instead of one per tensor.
+//                    Algorithmic bytes: 16 B read + 12 B written per parameter.
+#include "common.h"
+#include <math.h>
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int64_t stride,
+                                                           int n_slabs, float* __restrict__ dst, int64_t len4) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len4; e += (int64_t)gridDim.x * blockDim.x) {
+        float4 acc = f4_zero();
+        const float* p = slabs + e * 4;
+        int s = 0;
+        for (; s + 4 <= n_slabs; s += 4) {       // 4 independent loads in flight per lane
+            const float4 a = ld4(p), b = ld4(p + stride), c = ld4(p + 2 * stride), d = ld4(p + 3 * stride);
+            acc = f4_add(acc, f4_add(f4_add(a, b), f4_add(c, d)));
+            p += 4 * stride;
+        }
+        for (; s < n_slabs; ++s) { acc = f4_add(acc, ld4(p)); p += stride; }
+        st4(dst + e * 4, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                   float beta1, float beta2, float eps, float step_size,
+                                                   float sqrt_bc2, float grad_scale) {
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    (void)beta1;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        float4 p = ld4(param + e * 4), g = ld4(grad + e * 4), mm = ld4(m + e * 4), vv = ld4(v + e * 4);
+        float* pp = &p.x; float* gp = &g.x; float* mp = &mm.x; float* vp = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gp[k] * grad_scale;
+            mp[k] = mp[k] + omb1 * (gk - mp[k]);            // exp_avg.lerp_(grad, 1-beta1)
+            vp[k] = vp[k] * beta2 + omb2 * gk * gk;
+            const float denom = sqrtf(vp[k]) / sqrt_bc2 + eps;
+            pp[k] -= step_size * (mp[k] / denom);
+        }
+        st4(param + e * 4, p); st4(m + e * 4, mm); st4(v + e * 4, vv);
+    }
+}
+
+static unsigned stream_blocks(int64_t n4) {
+    int64_t b = (n4 + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+extern "C" int vlg_reduce_slabs(const float* slabs, int64_t slab_stride, int n_slabs, float* dst, int64_t len,
+                                void* stream) {
+    if (n_slabs < 1 || len < 4 || (len & 3) || (slab_stride & 3) || slab_stride < len) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(slabs) || !vlg_aligned16(dst)) return VLG_ERR_ALIGN;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(stream_blocks(len / 4)), dim3(256), 0, (hipStream_t)stream, slabs,
+                       slab_stride, n_slabs, dst, len / 4);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             int step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                             void* stream) {
+    if (n < 4 || (n & 3) || step < 1) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(param) || !vlg_aligned16(grad) || !vlg_aligned16(exp_avg) || !vlg_aligned16(exp_avg_sq))
+        return VLG_ERR_ALIGN;
+    // bias corrections in double, as torch.optim.Adam computes them on the host
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float sqrt_bc2 = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n / 4, beta1, beta2, eps, step_size, sqrt_bc2, grad_scale);
+    return vlg_last_error();
+}

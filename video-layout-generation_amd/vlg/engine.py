@@ -1,0 +1,276 @@
+"""Hand-scheduled training step of the layout-token model on one MI355X.
+
+No autograd, no tracing compiler: forward and backward are explicit sequences of
+launches of the gfx950 kernels in libvlg_hip.so on the caller's HIP stream, over
+buffers allocated once (parameters, gradients and Adam moments are single flat
+fp32 buffers; activations live in a preallocated workspace sized for the largest
+batch).  PyTorch supplies device memory and streams only.
+
+Step order mirrors the reference's Trainer.train() body (reference
+src/trainer.py:209-258): forward -> weighted loss (40/20/10) -> backward ->
+[gradient all-reduce by the caller] -> Adam.  Gradients are overwritten every
+step, i.e. the zero_grad() the reference forgot is implied.
+
+Row order of every (M, .) activation is the internal  m = (b*N + n)*T + t.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import hip
+from .hip import EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, call, ptr
+from .spec import (ADAM_BETA1, ADAM_BETA2, ADAM_EPS, ADAM_LR, BOX_DIM, IOU_EPS, LN_EPS, LOSS_W_CE,
+                   LOSS_W_REG, LOSS_W_STRUCT, SMOOTH_L1_BETA, LayoutConfig, param_layout)
+
+
+def init_params(cfg: LayoutConfig, seed: int) -> Dict[str, torch.Tensor]:
+    """Deterministic CPU initialisation (one generator, tensors in flat-buffer order).
+
+    Embedding tables ~ N(0,1) (nn.Embedding default, reference src/models/simple.py:23),
+    projections ~ U(+-1/sqrt(fan_in)) for weight and bias (nn.Linear default),
+    layer-norm gain 1 / bias 0.  Every rank uses the same seed, as the reference does
+    (src/main.py:57-60), so replicas start identical without a broadcast.
+    """
+    layout, _ = param_layout(cfg)
+    g = torch.Generator().manual_seed(seed)
+    fan_in = {name[:-2] + "_b": shape[1] for name, (_, shape) in layout.items() if name.endswith("_w")}
+    out: Dict[str, torch.Tensor] = {}
+    for name, (_, shape) in layout.items():
+        base = name.split(".")[-1]
+        if base in ("cls_emb", "time_emb"):
+            t = torch.randn(shape, generator=g, dtype=torch.float32)
+        elif base.endswith("_g"):
+            t = torch.ones(shape)
+        elif base.startswith("ln") and base.endswith("_b"):
+            t = torch.zeros(shape)
+        elif base.endswith("_w"):
+            t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) / math.sqrt(shape[1])
+        else:
+            t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) / math.sqrt(fan_in[name])
+        out[name] = t
+    return out
+
+
+class LayoutEngine:
+    """Owns parameters, optimiser state and workspace; runs forward/backward/Adam."""
+
+    def __init__(self, cfg: LayoutConfig, device: torch.device, seed: int = 1024,
+                 lr: float = ADAM_LR, beta1: float = ADAM_BETA1):
+        cfg.validate()
+        hip.load()                                   # fail loudly before touching the GPU
+        if device.type != "cuda":
+            raise hip.HipError("LayoutEngine needs a HIP device (got %s); there is no CPU path" % device)
+        self.cfg, self.device = cfg, device
+        self.lr, self.beta1 = float(lr), float(beta1)
+        self.layout, self.n_params = param_layout(cfg)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.params = torch.zeros(self.n_params, **f32)
+        self.grads = torch.zeros(self.n_params, **f32)
+        self.exp_avg = torch.zeros(self.n_params, **f32)
+        self.exp_avg_sq = torch.zeros(self.n_params, **f32)
+        self.step_count = 0
+        self.load_params(init_params(cfg, seed))
+        self._alloc_workspace(cfg.tokens)
+        self.loss_out = torch.zeros(4, **f32)        # {total, smooth_l1, iou, ce}
+
+    # ------------------------------------------------------------------ parameters
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        off, shape = self.layout[name]
+        return flat[off:off + math.prod(shape)].view(shape)
+
+    def p(self, name: str) -> torch.Tensor:
+        return self.view(self.params, name)
+
+    def g(self, name: str) -> torch.Tensor:
+        return self.view(self.grads, name)
+
+    def load_params(self, tensors: Dict[str, torch.Tensor]) -> None:
+        for name in self.layout:
+            self.p(name).copy_(tensors[name].to(torch.float32))
+
+    def named_params(self) -> Dict[str, torch.Tensor]:
+        return {n: self.p(n) for n in self.layout}
+
+    def named_grads(self) -> Dict[str, torch.Tensor]:
+        return {n: self.g(n) for n in self.layout}
+
+    def state_dict(self) -> Dict[str, object]:
+        return {"params": self.params.detach().cpu().clone(), "exp_avg": self.exp_avg.cpu().clone(),
+                "exp_avg_sq": self.exp_avg_sq.cpu().clone(), "step": self.step_count,
+                "layout": {k: (o, tuple(s)) for k, (o, s) in self.layout.items()}}
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        if tuple(sd["params"].shape) != (self.n_params,):
+            raise ValueError("checkpoint has %d parameters, model has %d" % (sd["params"].numel(), self.n_params))
+        self.params.copy_(sd["params"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+
+    # ------------------------------------------------------------------- workspace
+    def _alloc_workspace(self, tokens: int) -> None:
+        cfg, d, ff = self.cfg, self.cfg.d, self.cfg.d_ff
+        f32 = dict(dtype=torch.float32, device=self.device)
+        M = self.capacity = tokens
+        L = cfg.n_layers
+        lib = hip.load()
+        self.x = torch.empty(L + 1, M, d, **f32)          # residual stream entering each layer (+ final)
+        self.h1 = torch.empty(L, M, d, **f32)
+        self.qkv = torch.empty(L, M, 3 * d, **f32)
+        self.att = torch.empty(L, M, d, **f32)
+        self.xmid = torch.empty(L, M, d, **f32)
+        self.h2 = torch.empty(L, M, d, **f32)
+        self.u = torch.empty(L, M, ff, **f32)             # FFN pre-activation
+        self.gl = torch.empty(L, M, ff, **f32)            # gelu(u)
+        self.stats = torch.empty(2 * L + 1, 2, M, **f32)  # mean / rstd of every layer-norm
+        self.xf = torch.empty(M, d, **f32)
+        self.out = torch.empty(M, cfg.n_out, **f32)
+        self.dout = torch.empty(M, cfg.n_out, **f32)
+        self.dx = torch.empty(M, d, **f32)
+        self.dh = torch.empty(M, d, **f32)
+        self.du = torch.empty(M, ff, **f32)
+        self.dqkv = torch.empty(M, 3 * d, **f32)
+        self.loss_scratch = torch.zeros(lib.vlg_layout_loss_scratch(), **f32)
+        # one slab arena shared by every partial-sum producer (each is reduced before the next writes)
+        emb_len = self.layout["l0.ln1_g"][0]
+        need = [lib.vlg_embed_bwd_slabs() * emb_len, lib.vlg_layernorm_bwd_slabs(M) * 2 * d]
+        for (n, k) in ((3 * d, d), (d, d), (ff, d), (d, ff), (cfg.n_out, d)):
+            need.append(lib.vlg_linear_wgrad_slabs(M, n, k) * (n * k + n))
+        self.slabs = torch.empty(max(need), **f32)
+
+    # --------------------------------------------------------------------- helpers
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def _linear(self, a, w, b, c, M, N, K, epi, aux_in=None, aux_out=None):
+        call("vlg_linear_fwd", ptr(a), K, ptr(w), K, ptr(b), ptr(c), N, ptr(aux_in), ptr(aux_out), M, N, K, epi,
+             self._stream())
+
+    def _dgrad(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux_in=None):
+        call("vlg_linear_dgrad", ptr(dy), N, ptr(w), K, ptr(dx), K, ptr(aux_in), M, N, K, epi, self._stream())
+
+    def _wgrad(self, dy, x, wname, M, N, K):
+        """grad[w | b] = (dy^T . x | colsum dy): split partials -> slab arena -> flat gradient."""
+        lib = hip.load()
+        stride = N * K + N
+        n_slabs = lib.vlg_linear_wgrad_slabs(M, N, K)
+        s = self._stream()
+        call("vlg_linear_wgrad", ptr(dy), N, ptr(x), K, ptr(self.slabs), stride, M, N, K, s)
+        off = self.layout[wname][0]
+        call("vlg_reduce_slabs", ptr(self.slabs), stride, n_slabs, self.grads.data_ptr() + 4 * off, stride, s)
+
+    def _ln_fwd(self, x, gname, y, stat, M):
+        d = self.cfg.d
+        call("vlg_layernorm_fwd", ptr(x), ptr(self.p(gname)), ptr(self.p(gname[:-1] + "b")), ptr(y), ptr(stat[0]),
+             ptr(stat[1]), M, d, LN_EPS, self._stream())
+
+    def _ln_bwd(self, dy, x, stat, gname, dres, dx_out, M):
+        d = self.cfg.d
+        lib = hip.load()
+        n_slabs = lib.vlg_layernorm_bwd_slabs(M)
+        s = self._stream()
+        call("vlg_layernorm_bwd", ptr(dy), ptr(x), ptr(stat[0]), ptr(stat[1]), ptr(self.p(gname)), ptr(dres),
+             ptr(dx_out), ptr(self.slabs), 2 * d, M, d, s)
+        off = self.layout[gname][0]
+        call("vlg_reduce_slabs", ptr(self.slabs), 2 * d, n_slabs, self.grads.data_ptr() + 4 * off, 2 * d, s)
+
+    def _check_batch(self, batch) -> tuple:
+        sc = batch["slot_class"]
+        B, T, N = sc.shape
+        if T != self.cfg.T:
+            raise ValueError("batch has T=%d, engine was built for T=%d" % (T, self.cfg.T))
+        M = B * T * N
+        if M > self.capacity:
+            raise ValueError("batch of %d tokens exceeds workspace capacity %d" % (M, self.capacity))
+        for k, dt in (("slot_class", torch.int64), ("slot_box", torch.float32), ("tgt_class", torch.int64),
+                      ("tgt_box", torch.float32), ("valid", torch.float32)):
+            t = batch[k]
+            if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("batch[%r] must be a contiguous %s HIP tensor" % (k, dt))
+        return B, T, N, M
+
+    # --------------------------------------------------------------------- forward
+    def forward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Forward + fused loss (the loss kernel also leaves d(total)/d(out) in self.dout).
+        Returns the device tensor {total, smooth_l1, iou, ce}."""
+        cfg, d, ff = self.cfg, self.cfg.d, self.cfg.d_ff
+        B, T, N, M = self._check_batch(batch)
+        self._shape = (B, T, N, M)
+        s = self._stream()
+        call("vlg_embed_fwd", ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.p("cls_emb")),
+             ptr(self.p("box_w")), ptr(self.p("box_b")), ptr(self.p("time_emb")), ptr(self.x[0]),
+             B, T, N, d, cfg.vocab, s)
+        for l in range(cfg.n_layers):
+            pre = "l%d." % l
+            x = self.x[l]
+            self._ln_fwd(x, pre + "ln1_g", self.h1[l], self.stats[2 * l], M)
+            self._linear(self.h1[l], self.p(pre + "qkv_w"), self.p(pre + "qkv_b"), self.qkv[l], M, 3 * d, d, EPI_BIAS)
+            call("vlg_attention_fwd", ptr(self.qkv[l]), ptr(self.att[l]), B * N, T, d, s)
+            self._linear(self.att[l], self.p(pre + "proj_w"), self.p(pre + "proj_b"), self.xmid[l], M, d, d,
+                         EPI_BIAS | EPI_RESID, aux_in=x)
+            self._ln_fwd(self.xmid[l], pre + "ln2_g", self.h2[l], self.stats[2 * l + 1], M)
+            self._linear(self.h2[l], self.p(pre + "ff1_w"), self.p(pre + "ff1_b"), self.gl[l], M, ff, d,
+                         EPI_BIAS | EPI_GELU, aux_out=self.u[l])
+            self._linear(self.gl[l], self.p(pre + "ff2_w"), self.p(pre + "ff2_b"), self.x[l + 1], M, d, ff,
+                         EPI_BIAS | EPI_RESID, aux_in=self.xmid[l])
+        L = cfg.n_layers
+        self._ln_fwd(self.x[L], "lnf_g", self.xf, self.stats[2 * L], M)
+        self._linear(self.xf, self.p("head_w"), self.p("head_b"), self.out, M, cfg.n_out, d, EPI_BIAS)
+        call("vlg_layout_loss", ptr(self.out), cfg.n_out, ptr(batch["tgt_class"]), ptr(batch["tgt_box"]),
+             ptr(batch["valid"]), ptr(self.dout), ptr(self.loss_out), ptr(self.loss_scratch), B, T, N,
+             cfg.n_classes, SMOOTH_L1_BETA, IOU_EPS, LOSS_W_REG, LOSS_W_STRUCT, LOSS_W_CE, s)
+        return self.loss_out
+
+    # -------------------------------------------------------------------- backward
+    def backward(self, batch: Dict[str, torch.Tensor]) -> None:
+        """Fills self.grads (every element overwritten) from the state forward() left."""
+        cfg, d, ff = self.cfg, self.cfg.d, self.cfg.d_ff
+        B, T, N, M = self._shape
+        s = self._stream()
+        L = cfg.n_layers
+        self._wgrad(self.dout, self.xf, "head_w", M, cfg.n_out, d)
+        self._dgrad(self.dout, self.p("head_w"), self.dh, M, cfg.n_out, d)
+        self._ln_bwd(self.dh, self.x[L], self.stats[2 * L], "lnf_g", None, self.dx, M)
+        for l in reversed(range(L)):
+            pre = "l%d." % l
+            # FFN:  x_out = xmid + W2 gelu(W1 h2 + b1) + b2
+            self._wgrad(self.dx, self.gl[l], pre + "ff2_w", M, d, ff)
+            self._dgrad(self.dx, self.p(pre + "ff2_w"), self.du, M, d, ff, EPI_DGELU, aux_in=self.u[l])
+            self._wgrad(self.du, self.h2[l], pre + "ff1_w", M, ff, d)
+            self._dgrad(self.du, self.p(pre + "ff1_w"), self.dh, M, ff, d)
+            self._ln_bwd(self.dh, self.xmid[l], self.stats[2 * l + 1], pre + "ln2_g", self.dx, self.dx, M)
+            # attention:  xmid = x + Wo attn(Wqkv h1 + b) + bo
+            self._wgrad(self.dx, self.att[l], pre + "proj_w", M, d, d)
+            self._dgrad(self.dx, self.p(pre + "proj_w"), self.dh, M, d, d)
+            call("vlg_attention_bwd", ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s)
+            self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d)
+            self._dgrad(self.dqkv, self.p(pre + "qkv_w"), self.dh, M, 3 * d, d)
+            self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)
+        lib = hip.load()
+        emb_len = self.layout["l0.ln1_g"][0]
+        call("vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.slabs),
+             emb_len, B, T, N, d, cfg.vocab, s)
+        call("vlg_reduce_slabs", ptr(self.slabs), emb_len, lib.vlg_embed_bwd_slabs(), ptr(self.grads), emb_len, s)
+
+    def forward_backward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        loss = self.forward(batch)
+        self.backward(batch)
+        return loss
+
+    # ------------------------------------------------------------------- optimiser
+    def adam_step(self, grad_scale: float = 1.0) -> None:
+        """torch.optim.Adam(lr, betas=(beta1, 0.999)) on the flat buffer (reference src/trainer.py:83,258)."""
+        self.step_count += 1
+        call("vlg_adam_step", ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+             self.n_params, self.step_count, self.lr, self.beta1, ADAM_BETA2, ADAM_EPS, grad_scale, self._stream())
+
+    # ---------------------------------------------------------------- public views
+    def outputs_btn(self) -> tuple:
+        """(class logits (B,T,N,C), raw boxes (B,T,N,4)) of the last forward, in public order."""
+        B, T, N, M = self._shape
+        o = self.out[:M].view(B, N, T, self.cfg.n_out).permute(0, 2, 1, 3)
+        return o[..., :self.cfg.n_classes], o[..., self.cfg.n_classes:]

@@ -1,0 +1,87 @@
+"""ctypes binding of libvlg_hip.so (C ABI declared in include/vlg_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a kernel
+launch reports an error this module raises.  The product path never computes on
+the CPU and never imports anything from oracle/.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvlg_hip.so")
+
+EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU = 0, 1, 2, 4, 8
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes); must list every symbol include/vlg_hip.h declares
+SIGNATURES = {
+    "vlg_abi_version": (I, []),
+    "vlg_build_arch": (c_char_p, []),
+    "vlg_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "vlg_embed_bwd_slabs": (I, []),
+    "vlg_embed_bwd": (I, [P, P, P, P, L, I, I, I, I, I, P]),
+    "vlg_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
+    "vlg_layernorm_bwd_slabs": (I, [L]),
+    "vlg_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, L, L, I, P]),
+    "vlg_linear_fwd": (I, [P, I, P, I, P, P, I, P, P, L, I, I, I, P]),
+    "vlg_linear_dgrad": (I, [P, I, P, I, P, I, P, L, I, I, I, P]),
+    "vlg_linear_wgrad_slabs": (I, [L, I, I]),
+    "vlg_linear_wgrad": (I, [P, I, P, I, P, L, L, I, I, P]),
+    "vlg_attention_fwd": (I, [P, P, L, I, I, P]),
+    "vlg_attention_bwd": (I, [P, P, P, L, I, I, P]),
+    "vlg_layout_loss_scratch": (I, []),
+    "vlg_layout_loss": (I, [P, I, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, P]),
+    "vlg_reduce_slabs": (I, [P, L, I, P, L, P]),
+    "vlg_adam_step": (I, [P, P, P, P, L, I, F, F, F, F, F, P]),
+    "vlg_image_loss_scratch": (I, []),
+    "vlg_ce_nchw": (I, [P, P, P, P, P, I, I, L, F, P]),
+    "vlg_l1_mean": (I, [P, P, P, P, P, L, F, P]),
+    "vlg_gradient_loss": (I, [P, P, P, P, P, I, I, I, F, P]),
+    "vlg_ssim_loss": (I, [P, P, P, P, P, I, I, I, I, F, P]),
+    "vlg_prep_input": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libvlg_hip.so and type every entry point; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipError(
+            "libvlg_hip.so not found at %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C video-layout-generation_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_ERR = {1001: "VLG_ERR_SHAPE (unsupported or inconsistent shape)", 1002: "VLG_ERR_ALIGN (pointer / leading dimension not 16-byte aligned)"}
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise HipError("%s failed: %s" % (what, _ERR.get(code, "hipError_t %d" % code)))
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)
