@@ -48,7 +48,8 @@ def test_embed_fwd_bwd(H, dev, B, T, N, d):
     want.backward(gy)
     pd = {k: v.to(dev) for k, v in p.items()}
     x = torch.empty(B * N * T, d, device=dev)
-    H.call("vlg_embed_fwd", cls.to(dev).data_ptr(), box.to(dev).data_ptr(), pd["cls_emb"].data_ptr(),
+    clsd, boxd = cls.to(dev), box.to(dev)           # keep references: data_ptr() of a temporary dangles
+    H.call("vlg_embed_fwd", clsd.data_ptr(), boxd.data_ptr(), pd["cls_emb"].data_ptr(),
            pd["box_w"].data_ptr(), pd["box_b"].data_ptr(), pd["time_emb"].data_ptr(), x.data_ptr(),
            B, T, N, d, vocab, stream())
     got = x.view(B, N, T, d).permute(0, 2, 1, 3)
@@ -58,7 +59,6 @@ def test_embed_fwd_bwd(H, dev, B, T, N, d):
     L = vocab * d + d * 4 + d + T * d
     ns = H.load().vlg_embed_bwd_slabs()
     slabs = torch.empty(ns * L, device=dev)
-    clsd, boxd = cls.to(dev), box.to(dev)
     H.call("vlg_embed_bwd", dx.data_ptr(), clsd.data_ptr(), boxd.data_ptr(), slabs.data_ptr(), L, B, T, N, d, vocab,
            stream())
     g = reduce_slabs(H, slabs, L, ns, L, dev)

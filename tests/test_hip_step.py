@@ -56,22 +56,34 @@ def test_step_matches_oracle(dev, kw, variable_n):
 
 
 def test_three_adam_steps_track_oracle(dev):
-    """Parameters after 3 full steps (new batch each step) stay within 1e-4 of the oracle's."""
+    """Parameters after 3 full steps (new batch each step) track the oracle's.
+
+    Adam divides by sqrt(v): an element whose true gradient is ~0 (e.g. the key bias, to which
+    softmax is invariant) gets a +-lr update made of rounding noise on BOTH sides, so such
+    elements are excluded; every element with a gradient above 1e-3 of the tensor's max in all
+    three steps must agree to 1e-4 relative / 1e-6 absolute."""
     from vlg.spec import LayoutConfig, ADAM_LR, ADAM_BETA1
     cfg = LayoutConfig(B=2, T=8, N=8, d=64, n_layers=2)
     eng, p = build(cfg, dev)
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(x) for k, x in p.items()}
+    signal = {k: torch.ones_like(x, dtype=torch.bool) for k, x in p.items()}
     for step in range(1, 4):
         batch = O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=100 + step)
         _, grads = O.loss_and_grads(p, batch, cfg.n_layers)
         for k in p:
+            signal[k] &= grads[k].abs() > 1e-3 * grads[k].abs().max()
             O.adam_step(p[k], grads[k], m[k], v[k], step, lr=ADAM_LR, beta1=ADAM_BETA1)
         eng.forward_backward(to_dev(batch, dev))
         eng.adam_step()
+    checked = 0
     for name, t in eng.named_params().items():
-        # Adam's first steps move every weight by ~lr regardless of gradient size, so compare absolutely
-        assert_close(t, p[name], rtol=1e-4, atol=2e-5, what="param " + name)
+        sel = signal[name]
+        checked += int(sel.sum())
+        assert_close(t.cpu()[sel], p[name][sel], rtol=1e-4, atol=1e-6, what="param " + name)
+        # and nothing, signal or not, moved by more than 3 steps of lr (+ rounding)
+        assert float((t.cpu() - p[name]).abs().max()) <= 2 * 3 * ADAM_LR * 1.01
+    assert checked > 0.5 * eng.n_params
 
 
 def test_full_size_properties(dev):

@@ -47,9 +47,9 @@ def init_params(cfg: LayoutConfig, seed: int) -> Dict[str, torch.Tensor]:
         elif base.startswith("ln") and base.endswith("_b"):
             t = torch.zeros(shape)
         elif base.endswith("_w"):
-            t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) / math.sqrt(shape[1])
+            t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * (1.0 / math.sqrt(shape[1]))
         else:
-            t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) / math.sqrt(fan_in[name])
+            t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * (1.0 / math.sqrt(fan_in[name]))
         out[name] = t
     return out
 
