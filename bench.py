@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Throughput of the layout-token training step on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + fused losses + backward + (bucketed RCCL gradient all-reduce) + Adam over one
+batch of synthetic clips already resident in HBM.  Workload at every N: (B,T,N_slots)=(32,16,64),
+d=256 per GPU (weak scaling: per-GPU clips fixed, global batch = 32 * N).  One JSON line on rank 0.
+
+Extra objects on the line:
+  roofline      the dominant kernel (by summed device time inside the timed steps, measured with
+                HIP events on the launch stream): algorithmic FLOP per launch / average launch
+                duration vs the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+  cpu_baseline  the CPU oracle's identical step (torch-CPU, all host cores) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "video-layout-generation_amd")]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+KERNEL_OF_FAMILY = {             # rocprofv3 kernel names (profiles/) for each timed family
+    "gemm_fwd": "gemm_f32_kernel<128,128,true,true,*,false>",
+    "gemm_dgrad": "gemm_f32_kernel<128,128,true,false,*,false>",
+    "gemm_wgrad": "gemm_f32_kernel<128,128,false,false,0,true>",
+    "gemm_head": "gemm_f32_kernel<128,32,..>/<32,128,..>",
+}
+
+
+def cpu_baseline(cfg, budget_s: float = 20.0):
+    """Times the CPU oracle (the only CPU implementation of this step: the reference has none)
+    on a bounded sample: same T, N, d, depth; fewer clips per step so it fits the budget."""
+    from oracle import layout_spec as O
+    from vlg.spec import param_shapes
+    # the GPU box gives a one-GPU job a 16-core share; more threads than that only oversubscribes
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(threads)
+    B = min(cfg.B, 2)
+    p = O.init_params(param_shapes(cfg), seed=1024)
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(x) for k, x in p.items()}
+    batch = O.synthetic_batch(B, cfg.T, cfg.N, seed=1024)
+
+    def step(i):
+        _, g = O.loss_and_grads(p, batch, cfg.n_layers)
+        for k in p:
+            O.adam_step(p[k], g[k], m[k], v[k], i)
+
+    step(1)                                   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step(n + 2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 8:
+            break
+    return {"value": round(B * n / el, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of %d clips (T=%d,N=%d,d=%d,L=%d), torch-CPU oracle fwd+bwd+Adam, %.1f s"
+                      % (n, B, cfg.T, cfg.N, cfg.d, cfg.n_layers, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--T", type=int, default=16)
+    ap.add_argument("--N", type=int, default=64)
+    ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path for the product")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=dev)   # nccl == RCCL on ROCm
+
+    from vlg.data import synthetic_clips, to_device
+    from vlg.dp import GradReducer, bucket_ranges
+    from vlg.engine import KernelTimer, LayoutEngine
+    from vlg.spec import LayoutConfig, SEED, step_flops
+
+    cfg = LayoutConfig(B=args.B, T=args.T, N=args.N, d=args.d, n_layers=args.layers)
+    eng = LayoutEngine(cfg, dev, seed=SEED)                    # same seed on every rank (reference main.py:57-60)
+    batch = to_device(synthetic_clips(cfg.B, cfg.T, cfg.N, seed=SEED + rank), dev)   # each rank its own clips
+    reducer = None
+    if world > 1:
+        reducer = GradReducer(eng.grads_ext, bucket_ranges(eng.layout, eng.n_params, cfg.n_layers))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step(batch, reducer)
+    if not args.no_kernel_timing:
+        eng.timer = KernelTimer()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step(batch, reducer)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = [float(x) for x in eng.loss_out.cpu()]
+    if world > 1:
+        loss = [x / world for x in loss]
+
+    if rank == 0:
+        clips = world * cfg.B * args.steps
+        fl = step_flops(cfg)
+        line = {
+            "metric": "training clips/sec at (B,T,N)=(32,16,64) d=256; 1/2/4/8-GPU scaling",
+            "value": round(clips / elapsed, 2), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "layout-token training step, (B,T,N)=(%d,%d,%d) clips per GPU, d=%d"
+                                   % (cfg.B, cfg.T, cfg.N, cfg.d),
+                       "global_batch": world * cfg.B, "parallelism": "dp%d" % world,
+                       "self_oracle_hyperparameters": cfg.describe(),
+                       "step_gflop": round(fl["fwd_bwd"] / 1e9, 1),
+                       "step_tflops": round(fl["fwd_bwd"] * args.steps / elapsed / 1e12, 2),
+                       "final_loss": [round(x, 5) for x in loss]},
+        }
+        roof = None
+        if eng.timer is not None:
+            summ = eng.timer.summary()
+            fam = max(summ, key=lambda k: summ[k]["total_ms"])
+            s = summ[fam]
+            achieved = s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get(fam)
+            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "kernel": KERNEL_OF_FAMILY[fam], "launches": s["launches"],
+                    "avg_launch_us": round(1e3 * s["avg_ms"], 2),
+                    "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
+                    "share_of_step": round(s["total_ms"] / (1e3 * elapsed), 4),
+                    "families": {k: {"avg_us": round(1e3 * v["avg_ms"], 2), "launches": v["launches"],
+                                     "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 2)}
+                                 for k, v in summ.items()}}
+        line["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

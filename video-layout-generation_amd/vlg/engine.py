@@ -68,13 +68,17 @@ class LayoutEngine:
         self.layout, self.n_params = param_layout(cfg)
         f32 = dict(dtype=torch.float32, device=device)
         self.params = torch.zeros(self.n_params, **f32)
-        self.grads = torch.zeros(self.n_params, **f32)
+        # 4 extra floats after the last parameter hold the loss scalars, so they travel inside the
+        # first gradient bucket of the data-parallel all-reduce (vlg/dp.py)
+        self.grads_ext = torch.zeros(self.n_params + 4, **f32)
+        self.grads = self.grads_ext[:self.n_params]
         self.exp_avg = torch.zeros(self.n_params, **f32)
         self.exp_avg_sq = torch.zeros(self.n_params, **f32)
         self.step_count = 0
         self.load_params(init_params(cfg, seed))
         self._alloc_workspace(cfg.tokens)
-        self.loss_out = torch.zeros(4, **f32)        # {total, smooth_l1, iou, ce}
+        self.loss_out = self.grads_ext[self.n_params:]   # {total, smooth_l1, iou, ce}
+        self.timer = None                            # optional KernelTimer (bench.py roofline leg)
 
     # ------------------------------------------------------------------ parameters
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
@@ -146,12 +150,22 @@ class LayoutEngine:
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
+    def _timed(self, family: str, flops: float, name: str, *args) -> None:
+        """Launch through the C ABI; when a timer is attached, bracket the launch with events on
+        the launch stream (torch's current stream IS the stream handed to the kernel)."""
+        if self.timer is None:
+            call(name, *args)
+        else:
+            with self.timer.section(family, flops):
+                call(name, *args)
+
     def _linear(self, a, w, b, c, M, N, K, epi, aux_in=None, aux_out=None):
-        call("vlg_linear_fwd", ptr(a), K, ptr(w), K, ptr(b), ptr(c), N, ptr(aux_in), ptr(aux_out), M, N, K, epi,
-             self._stream())
+        self._timed("gemm_fwd" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_fwd", ptr(a), K, ptr(w), K,
+                    ptr(b), ptr(c), N, ptr(aux_in), ptr(aux_out), M, N, K, epi, self._stream())
 
     def _dgrad(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux_in=None):
-        call("vlg_linear_dgrad", ptr(dy), N, ptr(w), K, ptr(dx), K, ptr(aux_in), M, N, K, epi, self._stream())
+        self._timed("gemm_dgrad", 2.0 * M * N * K, "vlg_linear_dgrad", ptr(dy), N, ptr(w), K, ptr(dx), K,
+                    ptr(aux_in), M, N, K, epi, self._stream())
 
     def _wgrad(self, dy, x, wname, M, N, K):
         """grad[w | b] = (dy^T . x | colsum dy): split partials -> slab arena -> flat gradient."""
@@ -159,7 +173,8 @@ class LayoutEngine:
         stride = N * K + N
         n_slabs = lib.vlg_linear_wgrad_slabs(M, N, K)
         s = self._stream()
-        call("vlg_linear_wgrad", ptr(dy), N, ptr(x), K, ptr(self.slabs), stride, M, N, K, s)
+        self._timed("gemm_wgrad" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_wgrad", ptr(dy), N, ptr(x),
+                    K, ptr(self.slabs), stride, M, N, K, s)
         off = self.layout[wname][0]
         call("vlg_reduce_slabs", ptr(self.slabs), stride, n_slabs, self.grads.data_ptr() + 4 * off, stride, s)
 
@@ -226,8 +241,10 @@ class LayoutEngine:
         return self.loss_out
 
     # -------------------------------------------------------------------- backward
-    def backward(self, batch: Dict[str, torch.Tensor]) -> None:
-        """Fills self.grads (every element overwritten) from the state forward() left."""
+    def backward(self, batch: Dict[str, torch.Tensor], reducer=None) -> None:
+        """Fills self.grads (every element overwritten) from the state forward() left.  `reducer`
+        (vlg.dp.GradReducer) is told as soon as each contiguous gradient bucket is complete so its
+        all-reduce overlaps the rest of backward."""
         cfg, d, ff = self.cfg, self.cfg.d, self.cfg.d_ff
         B, T, N, M = self._shape
         s = self._stream()
@@ -235,6 +252,8 @@ class LayoutEngine:
         self._wgrad(self.dout, self.xf, "head_w", M, cfg.n_out, d)
         self._dgrad(self.dout, self.p("head_w"), self.dh, M, cfg.n_out, d)
         self._ln_bwd(self.dh, self.x[L], self.stats[2 * L], "lnf_g", None, self.dx, M)
+        if reducer is not None:
+            reducer.ready("head")
         for l in reversed(range(L)):
             pre = "l%d." % l
             # FFN:  x_out = xmid + W2 gelu(W1 h2 + b1) + b2
@@ -250,15 +269,30 @@ class LayoutEngine:
             self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d)
             self._dgrad(self.dqkv, self.p(pre + "qkv_w"), self.dh, M, 3 * d, d)
             self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)
+            if reducer is not None:
+                reducer.ready("l%d" % l)
         lib = hip.load()
         emb_len = self.layout["l0.ln1_g"][0]
         call("vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.slabs),
              emb_len, B, T, N, d, cfg.vocab, s)
         call("vlg_reduce_slabs", ptr(self.slabs), emb_len, lib.vlg_embed_bwd_slabs(), ptr(self.grads), emb_len, s)
+        if reducer is not None:
+            reducer.ready("embed")
 
-    def forward_backward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def forward_backward(self, batch: Dict[str, torch.Tensor], reducer=None) -> torch.Tensor:
         loss = self.forward(batch)
-        self.backward(batch)
+        self.backward(batch, reducer)
+        return loss
+
+    def train_step(self, batch: Dict[str, torch.Tensor], reducer=None) -> torch.Tensor:
+        """forward -> loss -> backward (+ overlapped gradient all-reduce) -> Adam, as one call.
+        Returns the loss scalars (summed over ranks when a reducer is attached)."""
+        loss = self.forward_backward(batch, reducer)
+        if reducer is not None:
+            reducer.wait()
+            self.adam_step(reducer.grad_scale)
+        else:
+            self.adam_step()
         return loss
 
     # ------------------------------------------------------------------- optimiser
@@ -274,3 +308,39 @@ class LayoutEngine:
         B, T, N, M = self._shape
         o = self.out[:M].view(B, N, T, self.cfg.n_out).permute(0, 2, 1, 3)
         return o[..., :self.cfg.n_classes], o[..., self.cfg.n_classes:]
+
+
+class KernelTimer:
+    """HIP-event timing of selected launches on the launch stream (bench.py roofline leg).
+
+    Events are recorded on torch's current stream, which is the stream passed to the kernels,
+    so each start/end pair brackets exactly one launch; durations are read after a sync."""
+
+    def __init__(self):
+        self.records = {}          # family -> list of (start, end, flops)
+
+    class _Section:
+        def __init__(self, timer, family, flops):
+            self.t, self.family, self.flops = timer, family, flops
+
+        def __enter__(self):
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+        def __exit__(self, *a):
+            self.e.record()
+            self.t.records.setdefault(self.family, []).append((self.s, self.e, self.flops))
+
+    def section(self, family: str, flops: float):
+        return KernelTimer._Section(self, family, flops)
+
+    def summary(self):
+        """family -> {launches, avg_ms, total_ms, flops_per_launch} (call after a device sync)."""
+        out = {}
+        for fam, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            fl = [f for _, _, f in recs]
+            out[fam] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms),
+                        "flops_per_launch": sum(fl) / len(fl)}
+        return out
