@@ -114,6 +114,18 @@ class LayoutEngine:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
 
+    def optimizer_state(self) -> Dict[str, object]:
+        """Adam state for the checkpoint's 'optimizer' entry (flat tensors, CPU)."""
+        return {"exp_avg": self.exp_avg.cpu().clone(), "exp_avg_sq": self.exp_avg_sq.cpu().clone(),
+                "step": int(self.step_count), "lr": self.lr, "beta1": self.beta1}
+
+    def load_optimizer(self, st: Dict[str, object]) -> None:
+        if st["exp_avg"].numel() != self.n_params:
+            raise ValueError("optimizer state has %d elements, model has %d" % (st["exp_avg"].numel(), self.n_params))
+        self.exp_avg.copy_(st["exp_avg"])
+        self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        self.step_count = int(st["step"])
+
     # ------------------------------------------------------------------- workspace
     def _alloc_workspace(self, tokens: int) -> None:
         cfg, d, ff = self.cfg, self.cfg.d, self.cfg.d_ff
