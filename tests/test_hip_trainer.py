@@ -1,0 +1,47 @@
+"""GPU: the real Trainer (HIP engine) driven the way reference src/main.py:62-82 drives it, side by
+side with the same Trainer on the oracle-backed double: same clips, same flips, same Adam -> the
+validation losses must agree to 1e-4."""
+import random
+
+import pytest
+import torch
+
+from helpers import oracle_factory, reference_args
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(batch_size=4, epochs=2, print_freq=1, n_frames=8, n_slots=8, d_model=64, n_layers=2,
+             train_clips=16, val_clips=8)
+
+
+def run(tmp, tag, factory):
+    from trainer import Trainer
+    random.seed(1024)                                       # main.worker seeds the shared flip stream (main.py:57)
+    args = reference_args(tmp / tag, **SMALL)
+    tr = Trainer(args, engine_factory=factory)
+    vals = []
+    for epoch in range(args.epochs):
+        tr.set_epoch(epoch)
+        tr.train()
+        vals.append(tr.validate()["loss"])
+    return tr, vals
+
+
+def test_trainer_on_gpu_matches_oracle_trainer(tmp_path, monkeypatch):
+    src = tmp_path / "src"
+    src.mkdir()
+    monkeypatch.chdir(src)
+    hip_tr, hip_vals = run(tmp_path, "hip", None)
+    assert hip_tr.device.type == "cuda"
+    cpu_tr, cpu_vals = run(tmp_path, "cpu", oracle_factory)
+    for a, b in zip(hip_vals, cpu_vals):
+        assert abs(a - b) <= 1e-4 * abs(b), (hip_vals, cpu_vals)
+    assert hip_vals[1] < hip_vals[0]
+    # checkpoint written by the HIP trainer restores into a fresh one bit for bit
+    hip_tr.save_checkpoint({"loss": hip_vals[-1]})
+    from trainer import Trainer
+    again = Trainer(reference_args(tmp_path / "again", resume="../checkpoint/latest.pth", **SMALL))
+    assert torch.equal(again.engine.params, hip_tr.engine.params)
+    assert torch.equal(again.engine.exp_avg_sq, hip_tr.engine.exp_avg_sq)
+    c, b = again.generate_sequence(*[next(iter(again.val_loader))[k] for k in ("slot_class", "slot_box")], steps=8)
+    assert c.shape == (4, 8, 8) and b.shape == (4, 8, 8, 4) and bool(torch.isfinite(b).all())
