@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmark on one MI355X (development tool; not part of the product path).
+
+Times every kernel of the step at the metric shape with HIP events, interleaved rounds in one
+process (guide rule 24), and prints achieved TFLOP/s or GB/s against the algorithmic work.
+    python tools/kernel_bench.py [--rounds 5] [--only gemm]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "video-layout-generation_amd")]
+import torch  # noqa: E402
+
+from vlg import hip  # noqa: E402
+from vlg.hip import EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--T", type=int, default=16)
+    ap.add_argument("--N", type=int, default=64)
+    ap.add_argument("--d", type=int, default=256)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = hip.load()
+    S = torch.cuda.current_stream().cuda_stream
+    B, T, N, d = a.B, a.T, a.N, a.d
+    M, ff = B * T * N, 4 * d
+    r = lambda *s: torch.randn(*s, device=dev)
+    x_d, x_3d, x_ff, x_ff2 = r(M, d), r(M, 3 * d), r(M, ff), r(M, ff)
+    y_d, y_3d, y_ff = r(M, d), r(M, 3 * d), r(M, ff)
+    w_qkv, w_proj, w_ff1, w_ff2 = r(3 * d, d), r(d, d), r(ff, d), r(d, ff)
+    bias = r(ff)
+    slabs = torch.empty(64 * (ff * d + ff), device=dev)
+    red_dst = torch.empty(ff * d + ff, device=dev)            # reduce target: [w | b] of the largest projection
+    stats = r(2, M)
+    g = r(d)
+    cases = []
+
+    def add(name, work, unit, fn):
+        if a.only in name:
+            cases.append((name, work, unit, fn))
+
+    P = lambda t: t.data_ptr()
+    fl = lambda n, k: 2.0 * M * n * k
+    add("gemm fwd qkv  (bias)", fl(3 * d, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_qkv), d, P(bias), P(y_3d), 3 * d, 0, 0, M, 3 * d, d, EPI_BIAS, S))
+    add("gemm fwd proj (bias+resid)", fl(d, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_proj), d, P(bias), P(y_d), d, P(x_d), 0, M, d, d, EPI_BIAS | EPI_RESID, S))
+    add("gemm fwd ff1  (bias+gelu)", fl(ff, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_ff1), d, P(bias), P(y_ff), ff, 0, P(x_ff2), M, ff, d, EPI_BIAS | EPI_GELU, S))
+    add("gemm fwd ff2  (bias+resid)", fl(d, ff), "F", lambda: hip.call("vlg_linear_fwd", P(x_ff), ff, P(w_ff2), ff, P(bias), P(y_d), d, P(x_d), 0, M, d, ff, EPI_BIAS | EPI_RESID, S))
+    add("gemm dgrad qkv", fl(3 * d, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_3d), 3 * d, P(w_qkv), d, P(y_d), d, 0, M, 3 * d, d, EPI_NONE, S))
+    add("gemm dgrad proj", fl(d, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_proj), d, P(y_d), d, 0, M, d, d, EPI_NONE, S))
+    add("gemm dgrad ff1", fl(ff, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_ff), ff, P(w_ff1), d, P(y_d), d, 0, M, ff, d, EPI_NONE, S))
+    add("gemm dgrad ff2 (dgelu)", fl(d, ff), "F", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(y_ff), ff, P(x_ff2), M, d, ff, EPI_DGELU, S))
+    for nm, n, k, dy, xx in (("qkv", 3 * d, d, x_3d, x_d), ("proj", d, d, y_d, x_d), ("ff1", ff, d, x_ff, x_d), ("ff2", d, ff, x_d, x_ff)):
+        ns = lib.vlg_linear_wgrad_slabs(M, n, k)
+        add("gemm wgrad %-4s (%d slabs)" % (nm, ns), fl(n, k), "F", lambda n=n, k=k, dy=dy, xx=xx: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, M, n, k, S))
+        add("reduce wgrad %-4s" % nm, 4.0 * (n * k + n) * (ns + 1), "B", lambda n=n, k=k, ns=ns: hip.call("vlg_reduce_slabs", P(slabs), n * k + n, ns, P(red_dst), n * k + n, S))
+    add("attention fwd", 16.0 * M * d, "B", lambda: hip.call("vlg_attention_fwd", P(x_3d), P(y_d), B * N, T, d, S))
+    add("attention bwd", 28.0 * M * d, "B", lambda: hip.call("vlg_attention_bwd", P(x_3d), P(x_d), P(y_3d), B * N, T, d, S))
+    add("layernorm fwd", 8.0 * M * d, "B", lambda: hip.call("vlg_layernorm_fwd", P(x_d), P(g), P(g), P(y_d), P(stats[0]), P(stats[1]), M, d, 1e-5, S))
+    add("layernorm bwd", 16.0 * M * d, "B", lambda: hip.call("vlg_layernorm_bwd", P(x_d), P(y_d), P(stats[0]), P(stats[1]), P(g), P(x_d), P(y_d), P(slabs), 2 * d, M, d, S))
+
+    times = {c[0]: [] for c in cases}
+    for rnd in range(a.rounds + 1):
+        for name, work, unit, fn in cases:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()
+            s.record()
+            for _ in range(a.iters):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            if rnd:
+                times[name].append(s.elapsed_time(e) / a.iters)
+    for name, work, unit, fn in cases:
+        t = sorted(times[name])
+        med = t[len(t) // 2] * 1e-3
+        rate = work / med
+        print("%-32s %8.1f us (min %7.1f)  %s" % (name, med * 1e6, t[0] * 1e3,
+              "%6.1f TFLOP/s (%4.1f%% of 157.3)" % (rate / 1e12, rate / 1.573e12) if unit == "F"
+              else "%6.0f GB/s (%4.1f%% of 8000)" % (rate / 1e9, rate / 8e10)))
+
+
+if __name__ == "__main__":
+    main()

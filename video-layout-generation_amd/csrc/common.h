@@ -40,12 +40,29 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// exact (erf) GELU and its derivative, matching F.gelu's default
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU (erf form, F.gelu's default) and its derivative.  erf comes from Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, i.e. below fp32 resolution of the result) instead of libm's erff: one
+// v_exp_f32 + one v_rcp_f32 + 6 FMAs, and the SAME exponential exp(-x^2/2) serves the normal pdf
+// needed by the derivative.  These run in GEMM epilogues, so their VALU cost is on the critical path
+// of the store tail.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x);
+    const float e = __expf(-0.5f * x * x);                     // exp(-(x/sqrt2)^2)
+    const float t = __frcp_rn(1.0f + 0.3275911f * 0.70710678118654752f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float tail = 0.5f * poly * e;                        // 1 - Phi(|x|)
+    cdf = x >= 0.f ? 1.0f - tail : tail;
+    pdf = 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float c, p;
+    gelu_parts(x, c, p);
+    return x * c;
+}
 __device__ __forceinline__ float dgelu_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float c, p;
+    gelu_parts(x, c, p);
+    return c + x * p;
 }
 
 // block-wide sum of one float per thread; result valid in thread 0 (smem >= blockDim/64 floats)

@@ -42,13 +42,17 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     }
 }
 
-// TT = frames per clip (compile time so the frame-table sums stay in registers)
+// TT = frames per clip (compile time so the frame-table sums stay in registers).
+// blockDim = NG * d: thread (grp, c) owns channel c; the NG groups of a block walk different
+// (clip, slot) sequences so NG times more loads are in flight per CU, and are combined through LDS
+// in a fixed order at the end (reproducible).
 template <int TT>
 __global__ void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ slot_class,
                                  const float* __restrict__ slot_box, float* __restrict__ slabs,
-                                 int64_t slab_stride, int B, int N, int d, int vocab) {
-    extern __shared__ __attribute__((aligned(16))) float cls_acc[];   // [vocab][d]
-    const int c = threadIdx.x;                                         // blockDim.x == d
+                                 int64_t slab_stride, int B, int N, int d, int vocab, int rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // [NG][rows][d], rows = max(vocab, TT+5)
+    const int c = threadIdx.x % d, grp = threadIdx.x / d, NG = blockDim.x / d;
+    float* cls_acc = lds + (int64_t)grp * rows * d;
     for (int v = 0; v < vocab; ++v) cls_acc[v * d + c] = 0.f;
     float t_acc[TT];
 #pragma unroll
@@ -56,14 +60,17 @@ __global__ void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __
     float b_acc = 0.f, w_acc0 = 0.f, w_acc1 = 0.f, w_acc2 = 0.f, w_acc3 = 0.f;
 
     const int64_t n_seq = (int64_t)B * N;
-    for (int64_t seq = blockIdx.x; seq < n_seq; seq += gridDim.x) {
+    for (int64_t seq = (int64_t)blockIdx.x * NG + grp; seq < n_seq; seq += (int64_t)gridDim.x * NG) {
         const int64_t b = seq / N;
         const int n = (int)(seq - b * N);
+        float gv[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) gv[t] = dx[(seq * TT + t) * d + c];     // TT independent loads in flight
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            const float g = dx[(seq * TT + t) * d + c];
+            const float g = gv[t];
             const int64_t src = (b * TT + t) * N + n;
-            int64_t cls = slot_class[src];                     // wave-uniform: scalar load
+            int64_t cls = slot_class[src];
             cls = cls < 0 ? 0 : (cls >= vocab ? vocab - 1 : cls);
             const float4 bx = ld4(slot_box + src * 4);
             cls_acc[cls * d + c] += g;
@@ -73,14 +80,39 @@ __global__ void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __
         }
     }
     float* slab = slabs + (int64_t)blockIdx.x * slab_stride;
-    for (int v = 0; v < vocab; ++v) slab[v * d + c] = cls_acc[v * d + c];
-    int64_t off = (int64_t)vocab * d;
-    st4(slab + off + (int64_t)c * 4, make_float4(w_acc0, w_acc1, w_acc2, w_acc3));
-    off += (int64_t)d * 4;
-    slab[off + c] = b_acc;
-    off += d;
+    __syncthreads();
+    if (grp == 0) {
+        for (int v = 0; v < vocab; ++v) {
+            float s = 0.f;
+            for (int k = 0; k < NG; ++k) s += lds[((int64_t)k * rows + v) * d + c];
+            slab[v * d + c] = s;
+        }
+    }
+    __syncthreads();
+    // second round through the same LDS: the register accumulators (TT frame rows, bias, 4 box columns)
+    float* mine = lds + (int64_t)grp * rows * d;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) slab[off + (int64_t)t * d + c] = t_acc[t];
+    for (int t = 0; t < TT; ++t) mine[t * d + c] = t_acc[t];
+    mine[(TT + 0) * d + c] = b_acc;
+    mine[(TT + 1) * d + c] = w_acc0; mine[(TT + 2) * d + c] = w_acc1;
+    mine[(TT + 3) * d + c] = w_acc2; mine[(TT + 4) * d + c] = w_acc3;
+    __syncthreads();
+    if (grp == 0) {
+        float r[TT + 5];
+#pragma unroll
+        for (int j = 0; j < TT + 5; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < NG; ++k) s += lds[((int64_t)k * rows + j) * d + c];
+            r[j] = s;
+        }
+        int64_t off = (int64_t)vocab * d;
+        st4(slab + off + (int64_t)c * 4, make_float4(r[TT + 1], r[TT + 2], r[TT + 3], r[TT + 4]));
+        off += (int64_t)d * 4;
+        slab[off + c] = r[TT];
+        off += d;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) slab[off + (int64_t)t * d + c] = r[t];
+    }
 }
 
 extern "C" int vlg_embed_fwd(const int64_t* slot_class, const float* slot_box, const float* cls_emb,
@@ -106,16 +138,27 @@ extern "C" int vlg_embed_bwd(const float* dx, const int64_t* slot_class, const f
     const int64_t need = (int64_t)vocab * d + (int64_t)d * 4 + d + (int64_t)T * d;
     if (slab_stride < need || (slab_stride & 3)) return VLG_ERR_SHAPE;
     if (!vlg_aligned16(slot_box) || !vlg_aligned16(slabs)) return VLG_ERR_ALIGN;
-    const size_t lds = (size_t)vocab * d * sizeof(float);
-    if (lds > 64 * 1024) return VLG_ERR_SHAPE;
-    const dim3 grid(EMBED_BWD_SLABS), block(d);
+    const int rows = vocab > T + 5 ? vocab : T + 5;
+    int ng = 1024 / d;                                    // groups per block
+    while (ng > 1 && (size_t)ng * rows * d * sizeof(float) > 96 * 1024) ng >>= 1;
+    const size_t lds = (size_t)ng * rows * d * sizeof(float);
+    if (lds > 160 * 1024) return VLG_ERR_SHAPE;
+    const dim3 grid(EMBED_BWD_SLABS), block(ng * d);
     hipStream_t s = (hipStream_t)stream;
+#define EMBED_BWD_LAUNCH(TT)                                                                                    \
+    {                                                                                                           \
+        (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                            (int)lds);                                                                          \
+        hipLaunchKernelGGL(embed_bwd_kernel<TT>, grid, block, lds, s, dx, slot_class, slot_box, slabs,          \
+                           slab_stride, B, N, d, vocab, rows);                                                  \
+    }
     switch (T) {
-        case 4:  hipLaunchKernelGGL(embed_bwd_kernel<4>,  grid, block, lds, s, dx, slot_class, slot_box, slabs, slab_stride, B, N, d, vocab); break;
-        case 8:  hipLaunchKernelGGL(embed_bwd_kernel<8>,  grid, block, lds, s, dx, slot_class, slot_box, slabs, slab_stride, B, N, d, vocab); break;
-        case 16: hipLaunchKernelGGL(embed_bwd_kernel<16>, grid, block, lds, s, dx, slot_class, slot_box, slabs, slab_stride, B, N, d, vocab); break;
-        case 32: hipLaunchKernelGGL(embed_bwd_kernel<32>, grid, block, lds, s, dx, slot_class, slot_box, slabs, slab_stride, B, N, d, vocab); break;
+        case 4:  EMBED_BWD_LAUNCH(4) break;
+        case 8:  EMBED_BWD_LAUNCH(8) break;
+        case 16: EMBED_BWD_LAUNCH(16) break;
+        case 32: EMBED_BWD_LAUNCH(32) break;
         default: return VLG_ERR_SHAPE;
     }
+#undef EMBED_BWD_LAUNCH
     return vlg_last_error();
 }

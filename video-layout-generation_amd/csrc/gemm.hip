@@ -12,18 +12,21 @@
 // MFMA j of chunk s so ONE float4 read feeds four MFMAs (A and B use the same assignment,
 // the contraction order inside a chunk is free).
 // Block = 256 threads = 4 waves; 128x128 tile => each wave owns 64x64 = 2x2 MFMA tiles
-// (64 accumulator VGPRs).  BK = 32, register-staged double buffering (global loads for tile
-// k+1 are issued before the MFMAs of tile k, written to the other LDS buffer after them, one
-// barrier per tile).  73.7 KB LDS per block -> 2 blocks / CU, so one block's MFMAs cover the
-// other's staging.  blockIdx is remapped so tiles that share an A panel sit on one XCD (L2).
+// (64 accumulator VGPRs).  Staging is global -> VGPR -> LDS, double-buffered in LDS and one tile
+// deep in registers: tile kt+1 is loaded from global during tile kt-1's second half, written to the
+// idle LDS buffer in the MIDDLE of tile kt's MFMAs (behind a wait that is already satisfied), and
+// the loads for tile kt+2 are issued right after - so an iteration ends in a bare barrier with no
+// vmcnt wait and no ds_write burst on the critical path (+5-6 % over load-top / write-bottom).
+// BK (contraction depth per tile) is a template parameter: 32 -> 73.7 KB LDS, 2 blocks / CU;
+// 16 -> 41 KB, 3 blocks / CU.  blockIdx is remapped so tiles sharing an A panel sit on one XCD (L2).
+// Interior blocks take an unguarded instantiation of the main loop; edge blocks clamp + select.
 // Algorithmic work per launch: 2*M*N*K flop; bytes 4*(M*K + N*K + M*N) (+ aux operands).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define GEMM_BK 32
-#define GEMM_LDK 36          // padded row stride of a *_KC tile
 #define GEMM_THREADS 256
 
 struct GemmArgs {
@@ -35,40 +38,55 @@ struct GemmArgs {
     int lda, ldb, ldc;
     int tiles_m, tiles_n, splits;
     int64_t kc_per_split, slab_stride, colsum_off;
+    unsigned long long* clock_probe;   // diagnostic only (VLG_GEMM_CLOCK_PROBE): {shader ticks, 100 MHz ticks} per block
 };
 
-template <int BR, bool KC>
+// One operand tile: BR rows (non-contraction) x BK contraction steps.
+template <int BR, bool KC, int BK>
 struct Tile {
-    static constexpr int NV = BR / 32;                       // float4 per thread per tile
-    static constexpr int FLOATS = KC ? BR * GEMM_LDK : GEMM_BK * BR;
+    static constexpr int LDK = BK + 4;                                  // padded row stride of a KC tile
+    static constexpr int F4 = BR * BK / 4;                              // float4 per tile
+    static constexpr int NV = (F4 + GEMM_THREADS - 1) / GEMM_THREADS;   // float4 per thread
+    static constexpr int FLOATS = KC ? BR * LDK : BK * BR;
+    static constexpr int PER_ROW = KC ? BK / 4 : BR / 4;                // float4 per memory row
 
+    // GUARD = false: interior tile, plain loads that stay in flight until the LDS write.
+    // GUARD = true : edge tile; address clamped into the operand and the value zeroed by a select
+    //                (no branches).  Requires R >= 4 and kend - k0 >= 4 when anything is in range.
+    template <bool GUARD>
     __device__ static __forceinline__ void gload(float4 (&r)[NV], const float* __restrict__ P, int ld,
                                                  int64_t r0, int64_t R, int64_t k0, int64_t kend, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            if constexpr (KC) {
-                const int64_t gr = r0 + (tid >> 3) + 32 * i;
-                const int64_t gk = k0 + ((tid & 7) << 2);
-                r[i] = (gr < R && gk < kend) ? ld4(P + gr * ld + gk) : f4_zero();
+            const int idx = tid + GEMM_THREADS * i;
+            if (F4 % GEMM_THREADS != 0 && idx >= F4) { r[i] = f4_zero(); continue; }
+            const int major = idx / PER_ROW, minor = (idx % PER_ROW) << 2;
+            // KC: memory row = operand row, column = k.   MC: memory row = k, column = operand row.
+            const int64_t grow = KC ? r0 + major : k0 + major;
+            const int64_t gcol = KC ? k0 + minor : r0 + minor;
+            const int64_t rlim = KC ? R : kend, clim = KC ? kend : R;
+            if constexpr (GUARD) {
+                const bool ok = grow < rlim && gcol < clim;
+                const float4 v = ld4(P + (grow < rlim ? grow : rlim - 1) * ld + (gcol < clim ? gcol : clim - 4));
+                r[i] = ok ? v : f4_zero();
             } else {
-                const int idx = tid + GEMM_THREADS * i;
-                const int64_t gk = k0 + idx / (BR / 4);
-                const int64_t gc = r0 + ((idx % (BR / 4)) << 2);
-                r[i] = (gk < kend && gc < R) ? ld4(P + gk * ld + gc) : f4_zero();
+                r[i] = ld4(P + grow * ld + gcol);
             }
         }
     }
     __device__ static __forceinline__ void sstore(const float4 (&r)[NV], float* S, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            if constexpr (KC) st4(S + ((tid >> 3) + 32 * i) * GEMM_LDK + ((tid & 7) << 2), r[i]);
-            else st4(S + ((tid + GEMM_THREADS * i) << 2), r[i]);
+            const int idx = tid + GEMM_THREADS * i;
+            if (F4 % GEMM_THREADS != 0 && idx >= F4) continue;
+            if constexpr (KC) st4(S + (idx / PER_ROW) * LDK + ((idx % PER_ROW) << 2), r[i]);
+            else st4(S + (idx << 2), r[i]);
         }
     }
     // 4 fragment values of tile row `row` for chunk s, lane half h:  k = 8s + 4h + j
     __device__ static __forceinline__ void frag(float (&f)[4], const float* S, int row, int s, int h) {
         if constexpr (KC) {
-            const float4 t = ld4(S + row * GEMM_LDK + 8 * s + 4 * h);
+            const float4 t = ld4(S + row * LDK + 8 * s + 4 * h);
             f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
         } else {
 #pragma unroll
@@ -77,13 +95,14 @@ struct Tile {
     }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int WM = (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 4 : 1);
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-    using TA = Tile<BM, A_KC>;
-    using TB = Tile<BN, B_KC>;
+    constexpr int NCH = BK / 8;                    // 8-deep MFMA chunks per tile
+    using TA = Tile<BM, A_KC, BK>;
+    using TB = Tile<BN, B_KC, BK>;
     __shared__ __attribute__((aligned(16))) float smem[2 * (TA::FLOATS + TB::FLOATS)];
     float* const As0 = smem;                       // As[buf] = As0 + buf * TA::FLOATS
     float* const Bs0 = smem + 2 * TA::FLOATS;      // Bs[buf] = Bs0 + buf * TB::FLOATS
@@ -126,54 +145,73 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
         }
     }
 
+    unsigned long long t0 = 0, r0 = 0;
+    if (g.clock_probe) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     float4 ra[TA::NV], rb[TB::NV];
-    const int nk = (int)((kend - kbeg + GEMM_BK - 1) / GEMM_BK);
-    if (nk > 0) {
-        TA::gload(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid);
-        TB::gload(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
-        TA::sstore(ra, As0, tid);
-        TB::sstore(rb, Bs0, tid);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            const int64_t k0 = kbeg + (int64_t)(kt + 1) * GEMM_BK;
-            TA::gload(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
-            TB::gload(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+    auto chunk = [&](const float* as, const float* bs, int s) {
+        float a[TM][4], b[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) TA::frag(a[i], as, (wm * TM + i) * 32 + l31, s, h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) TB::frag(b[j], bs, (wn * TN + j) * 32 + l31, s, h);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+    };
+    auto mainloop = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+        if (nk > 0) {
+            TA::template gload<GUARD>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid);
+            TB::template gload<GUARD>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+            TA::sstore(ra, As0, tid);
+            TB::sstore(rb, Bs0, tid);
         }
-        const float* as = As0 + cur * TA::FLOATS;
-        const float* bs = Bs0 + cur * TB::FLOATS;
-#pragma unroll
-        for (int s = 0; s < GEMM_BK / 8; ++s) {
-            float a[TM][4], b[TN][4];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) TA::frag(a[i], as, (wm * TM + i) * 32 + l31, s, h);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) TB::frag(b[j], bs, (wn * TN + j) * 32 + l31, s, h);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
-        }
-        if constexpr (COLSUM) {
-            // bias gradient: column sums of the dY tile, taken once per row-tile (tn == 0)
-            if (tn == 0 && tid < BM) {
-#pragma unroll 8
-                for (int kk = 0; kk < GEMM_BK; ++kk) colacc += as[kk * BM + tid];
-            }
-        }
-        if (more) {
-            TA::sstore(ra, As0 + (cur ^ 1) * TA::FLOATS, tid);
-            TB::sstore(rb, Bs0 + (cur ^ 1) * TB::FLOATS, tid);
+        if (nk > 1) {
+            TA::template gload<GUARD>(ra, g.A, g.lda, m0, g.M, kbeg + BK, kend, tid);
+            TB::template gload<GUARD>(rb, g.B, g.ldb, n0, g.N, kbeg + BK, kend, tid);
         }
         __syncthreads();
-    }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const float* as = As0 + cur * TA::FLOATS;
+            const float* bs = Bs0 + cur * TB::FLOATS;
+#pragma unroll
+            for (int s = 0; s < NCH / 2; ++s) chunk(as, bs, s);
+            if (kt + 1 < nk) {
+                TA::sstore(ra, As0 + (cur ^ 1) * TA::FLOATS, tid);
+                TB::sstore(rb, Bs0 + (cur ^ 1) * TB::FLOATS, tid);
+            }
+            if (kt + 2 < nk) {
+                const int64_t k0 = kbeg + (int64_t)(kt + 2) * BK;
+                TA::template gload<GUARD>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
+                TB::template gload<GUARD>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+            }
+#pragma unroll
+            for (int s = NCH / 2; s < NCH; ++s) chunk(as, bs, s);
+            if constexpr (COLSUM) {
+                // bias gradient: column sums of the dY tile, taken once per row-tile (tn == 0)
+                if (tn == 0 && tid < BM) {
+#pragma unroll 8
+                    for (int kk = 0; kk < BK; ++kk) colacc += as[kk * BM + tid];
+                }
+            }
+            __syncthreads();
+        }
+    };
+    // interior blocks (every tile fully inside both operands) take the unguarded instantiation
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) % BK) == 0);
+    if (interior) mainloop(std::false_type{});
+    else mainloop(std::true_type{});
 
+    if (g.clock_probe && tid == 0) {
+        g.clock_probe[2 * bid] = __builtin_amdgcn_s_memtime() - t0;
+        g.clock_probe[2 * bid + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h.
     // 32 lanes of a half write one 128-B row segment per store.
     float* Cs = g.C + (int64_t)split * g.slab_stride;
@@ -216,14 +254,35 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     }
 }
 
+// diagnostic: a device buffer of 2 * blocks uint64 set through vlg_debug_set_clock_probe (NULL = off)
+static unsigned long long* vlg_gemm_clock_probe = nullptr;
+extern "C" void vlg_debug_set_clock_probe(unsigned long long* p) { vlg_gemm_clock_probe = p; }
+
+// development switch for tools/kernel_bench.py A/B runs: VLG_GEMM_BK = 16 | 32 (contraction depth per tile)
+static int gemm_bk() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VLG_GEMM_BK");
+        v = (e && atoi(e) == 16) ? 16 : 32;
+    }
+    return v;
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
 static int launch_gemm(GemmArgs g, hipStream_t s) {
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (g.N + BN - 1) / BN;
     const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.splits;
     if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
-    auto kern = gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, s, g);
+    const dim3 grid((unsigned)blocks), block(GEMM_THREADS);
+    g.clock_probe = vlg_gemm_clock_probe;
+    if constexpr (BM == 128 && BN == 128) {
+        if (gemm_bk() == 16) {
+            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, A_KC, B_KC, EPI, COLSUM>), grid, block, 0, s, g);
+            return vlg_last_error();
+        }
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM>), grid, block, 0, s, g);
     return vlg_last_error();
 }
 
@@ -282,12 +341,12 @@ extern "C" int vlg_linear_dgrad(const float* dY, int ldy, const float* W, int ld
 static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per) {
     const int bm = N <= 32 ? 32 : 128;
     const int64_t tiles = ((N + bm - 1) / bm) * (int64_t)((K + 127) / 128);
-    int64_t want = (512 + tiles - 1) / tiles;
+    int64_t want = 512 / tiles;                      // blocks <= 512 = 256 CUs x 2 resident blocks: one full wave, no tail
     const int64_t max_splits = (M + 255) / 256;
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;
     int64_t p = (M + want - 1) / want;
-    p = (p + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    p = (p + 31) / 32 * 32;
     *per = p;
     *splits = (int)((M + p - 1) / p);
 }

@@ -28,6 +28,36 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
 }
 
+// Many slabs, short vectors (layer-norm gain/bias: 512 slabs x 2d floats; embedding tables): the flat
+// kernel above would leave one block walking hundreds of slabs serially.  Here a block owns 16 float4
+// columns and its 256 threads split the slabs 16 ways, then combine through LDS in a fixed order
+// (still bitwise reproducible).
+__global__ __launch_bounds__(256) void reduce_slabs_tall_kernel(const float* __restrict__ slabs, int64_t stride,
+                                                                int n_slabs, float* __restrict__ dst, int64_t len4) {
+    __shared__ float4 part[16][16];
+    const int c = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const int64_t col = (int64_t)blockIdx.x * 16 + c;
+    float4 acc = f4_zero();
+    if (col < len4) {
+        const float* p = slabs + col * 4;
+        int s = sg;
+        for (; s + 48 < n_slabs; s += 64) {       // 4 independent loads in flight per lane
+            const float4 a = ld4(p + s * stride), b = ld4(p + (s + 16) * stride);
+            const float4 c2 = ld4(p + (s + 32) * stride), d = ld4(p + (s + 48) * stride);
+            acc = f4_add(acc, f4_add(f4_add(a, b), f4_add(c2, d)));
+        }
+        for (; s < n_slabs; s += 16) acc = f4_add(acc, ld4(p + s * stride));
+    }
+    part[sg][c] = acc;
+    __syncthreads();
+    if (sg == 0 && col < len4) {
+        float4 t = part[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t = f4_add(t, part[k][c]);
+        st4(dst + col * 4, t);
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                    float beta1, float beta2, float eps, float step_size,
@@ -60,8 +90,13 @@ extern "C" int vlg_reduce_slabs(const float* slabs, int64_t slab_stride, int n_s
                                 void* stream) {
     if (n_slabs < 1 || len < 4 || (len & 3) || (slab_stride & 3) || slab_stride < len) return VLG_ERR_SHAPE;
     if (!vlg_aligned16(slabs) || !vlg_aligned16(dst)) return VLG_ERR_ALIGN;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(stream_blocks(len / 4)), dim3(256), 0, (hipStream_t)stream, slabs,
-                       slab_stride, n_slabs, dst, len / 4);
+    const int64_t len4 = len / 4;
+    if (len4 < 32768 && n_slabs >= 16)         // fewer than 128 flat blocks: split the slabs across threads instead
+        hipLaunchKernelGGL(reduce_slabs_tall_kernel, dim3((unsigned)((len4 + 15) / 16)), dim3(256), 0,
+                           (hipStream_t)stream, slabs, slab_stride, n_slabs, dst, len4);
+    else
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(stream_blocks(len4)), dim3(256), 0, (hipStream_t)stream, slabs,
+                           slab_stride, n_slabs, dst, len4);
     return vlg_last_error();
 }
 

@@ -165,7 +165,7 @@ class LayoutEngine:
     def _timed(self, family: str, flops: float, name: str, *args) -> None:
         """Launch through the C ABI; when a timer is attached, bracket the launch with events on
         the launch stream (torch's current stream IS the stream handed to the kernel)."""
-        if self.timer is None:
+        if self.timer is None or (self.timer.only is not None and family not in self.timer.only):
             call(name, *args)
         else:
             with self.timer.section(family, flops):
@@ -328,8 +328,9 @@ class KernelTimer:
     Events are recorded on torch's current stream, which is the stream passed to the kernels,
     so each start/end pair brackets exactly one launch; durations are read after a sync."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = {}          # family -> list of (start, end, flops)
+        self.only = only           # None = every family, else a tuple of family names to bracket
 
     class _Section:
         def __init__(self, timer, family, flops):
