@@ -95,8 +95,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path for the product")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    distributed = world > 1 or "RANK" in os.environ          # under torch.distributed.run even at N=1
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=dev)   # nccl == RCCL on ROCm
 
     from vlg.data import synthetic_clips, to_device
@@ -108,12 +110,13 @@ def main():
     eng = LayoutEngine(cfg, dev, seed=SEED)                    # same seed on every rank (reference main.py:57-60)
     batch = to_device(synthetic_clips(cfg.B, cfg.T, cfg.N, seed=SEED + rank), dev)   # each rank its own clips
     reducer = None
-    if world > 1:
-        reducer = GradReducer(eng.grads_ext, bucket_ranges(eng.layout, eng.n_params, cfg.n_layers))
+    if distributed:
+        reducer = GradReducer(eng.grads_ext, bucket_ranges(eng.layout, eng.n_params, cfg.n_layers),
+                              always_communicate=True)
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -130,13 +133,11 @@ def main():
         eng.train_step(batch, reducer)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = [float(x) for x in eng.loss_out.cpu()]
-    if world > 1:
-        loss = [x / world for x in loss]
+    loss = [float(x) / world for x in eng.loss_out.cpu()]     # summed over ranks inside the first bucket
 
     if rank == 0:
         clips = world * cfg.B * args.steps
@@ -188,7 +189,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -191,6 +191,172 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// T = 16 fast path: no LDS at all.  A 16 x 16 score tile is exactly one v_mfma_f32_16x16x4_f32 tile,
+// so one wavefront keeps q, k, v (and dO) of its (slot, head) in registers, loaded straight from HBM
+// in the MFMA operand layouts, and every product is an exact-fp32 MFMA chain:
+//   row-style load   lane (r = l&15, g = l>>4) holds X[r][16f + 4g + e]   (f = float4 index, e = element)
+//                    -> as operand A it is X[row r][k], as operand B it is X[col r][k]: the SAME
+//                    registers give  S^T = K.Q^T  (A = K, B = Q)  and  S = Q.K^T  (A = Q, B = K)
+//   k-style load     lane (c = l&15, g = l>>4) holds X[4g + rho][4c + e], rho = 0..3
+//                    -> operand A of the products that contract over the 16 frames
+//   C/D layout       col = l&15, row = 4*(l>>4) + reg.  A score tile in this layout is ALREADY the B
+//                    operand of the next product (k-slot g <-> frame 4g + reg at MFMA step reg), so P
+//                    never moves between lanes (guide: "an accumulator tile as the next MFMA's operand").
+// With output-channel mapping  row c' of tile ct  <->  channel 4c' + ct, a lane ends up owning 16
+// consecutive channels of one frame: four float4 stores, 256 B contiguous per frame.
+// Softmax statistics are shuffle reductions (over lane groups for the transposed tile, over the 16
+// lanes of a group for the plain tile).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void load_rows16(float4 (&x)[4], const float* __restrict__ base, int64_t ld, int r, int g) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) x[f] = ld4(base + r * ld + 16 * f + 4 * g);
+}
+__device__ __forceinline__ void load_kmajor16(float4 (&x)[4], const float* __restrict__ base, int64_t ld, int c, int g) {
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) x[rho] = ld4(base + (4 * g + rho) * ld + 4 * c);
+}
+// D = sum_c A[.][c] * B[.][c] over the 64 channels held row-style (two chains to halve the latency)
+__device__ __forceinline__ f32x4 dot_rows16(const float4 (&a)[4], const float4 (&b)[4]) {
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        c0 = MFMA16(a[f].x, b[f].x, c0);
+        c1 = MFMA16(a[f].y, b[f].y, c1);
+        c0 = MFMA16(a[f].z, b[f].z, c0);
+        c1 = MFMA16(a[f].w, b[f].w, c1);
+    }
+    return c0 + c1;
+}
+// out[ct] (tile of 16 channels 4c'+ct x 16 columns) += sum_rho A_k[rho][ct] * Bt[rho]
+__device__ __forceinline__ void contract_frames16(f32x4 (&out)[4], const float4 (&ak)[4], const f32x4& bt) {
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+        out[0] = MFMA16(ak[rho].x, bt[rho], out[0]);
+        out[1] = MFMA16(ak[rho].y, bt[rho], out[1]);
+        out[2] = MFMA16(ak[rho].z, bt[rho], out[2]);
+        out[3] = MFMA16(ak[rho].w, bt[rho], out[3]);
+    }
+}
+// lane (col, g) stores its 16 consecutive channels 16g .. 16g+15 of row `col`
+__device__ __forceinline__ void store_tiles16(float* __restrict__ dst, const f32x4 (&o)[4]) {
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) st4(dst + 4 * rho, make_float4(o[0][rho], o[1][rho], o[2][rho], o[3][rho]));
+}
+// softmax of a TRANSPOSED tile: lane (i, g) holds scores of query i for keys j = 4g + reg
+__device__ __forceinline__ void softmax_t16(f32x4& s, int i, int g, float scale) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] = (4 * g + r <= i) ? s[r] * scale : -INFINITY; mx = fmaxf(mx, s[r]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] = expf(s[r] - mx); sum += s[r]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] *= inv;
+}
+// softmax of a PLAIN tile: lane (j, g) holds scores of key j for queries i = 4g + reg
+__device__ __forceinline__ void softmax_p16(f32x4& s, int j, int g, float scale) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = (j <= 4 * g + r) ? s[r] * scale : -INFINITY;
+        const float mx = group_max<16>(v);
+        v = expf(v - mx);
+        s[r] = v / group_sum<16>(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                         int d, int n_heads, int64_t n_items) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;                             // wave-uniform
+    const int64_t seq = item / n_heads;
+    const int hh = (int)(item - seq * n_heads);
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t ld = 3 * (int64_t)d;
+    const float* base = qkv + seq * 16 * ld + hh * HD;
+    float4 qf[4], kf[4], vk[4];
+    load_rows16(qf, base, ld, r, g);
+    load_rows16(kf, base + d, ld, r, g);
+    load_kmajor16(vk, base + 2 * d, ld, r, g);
+    f32x4 pt = dot_rows16(kf, qf);                            // S^T[j = 4g+reg][i = r]
+    softmax_t16(pt, r, g, 0.125f);
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    contract_frames16(acc, vk, pt);                           // O^T[c][i] = sum_j V[j][c] P^T[j][i]
+    store_tiles16(o + (seq * 16 + r) * (int64_t)d + hh * HD + 16 * g, acc);
+}
+
+__global__ __launch_bounds__(256) void attn16_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                         float* __restrict__ dqkv, int d, int n_heads, int64_t n_items) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const int64_t seq = item / n_heads;
+    const int hh = (int)(item - seq * n_heads);
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t ld = 3 * (int64_t)d;
+    const float* base = qkv + seq * 16 * ld + hh * HD;
+    const float* gbase = dout + seq * 16 * (int64_t)d + hh * HD;
+    const float scale = 0.125f;
+    f32x4 p, pt, ds, dst_;                                     // plain / transposed probabilities and dS
+    {
+        float4 qf[4], kf[4], vf[4], gf[4];
+        load_rows16(qf, base, ld, r, g);
+        load_rows16(kf, base + d, ld, r, g);
+        load_rows16(vf, base + 2 * d, ld, r, g);
+        load_rows16(gf, gbase, d, r, g);
+        pt = dot_rows16(kf, qf);                               // S^T : lane (i, g), keys 4g+reg
+        p = dot_rows16(qf, kf);                                // S   : lane (j, g), queries 4g+reg
+        f32x4 dpt = dot_rows16(vf, gf);                        // dP^T[j][i] = sum_c V[j][c] dO[i][c]
+        f32x4 dp = dot_rows16(gf, vf);                         // dP  [i][j]
+        softmax_t16(pt, r, g, scale);
+        softmax_p16(p, r, g, scale);
+        // delta_i = sum_j P[i][j] dP[i][j]
+        float dl = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dl += pt[k] * dpt[k];       // masked entries have P = 0 (dP there is finite)
+        dl += __shfl_xor(dl, 16);
+        dl += __shfl_xor(dl, 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst_[k] = pt[k] * (dpt[k] - dl) * scale;           // dS^T[j][i]
+            const float dk = group_sum<16>(p[k] * dp[k]);      // delta of query 4g+k, summed over the 16 key lanes
+            ds[k] = p[k] * (dp[k] - dk) * scale;               // dS[i][j]
+        }
+    }
+    float* obase = dqkv + (seq * 16 + r) * ld + hh * HD + 16 * g;
+    f32x4 acc[4];
+    float4 xk[4];
+    // dV[j][c] = sum_i P[i][j] dO[i][c]
+    load_kmajor16(xk, gbase, d, r, g);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    contract_frames16(acc, xk, p);
+    store_tiles16(obase + 2 * d, acc);
+    // dK[j][c] = sum_i dS[i][j] Q[i][c]
+    load_kmajor16(xk, base, ld, r, g);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    contract_frames16(acc, xk, ds);
+    store_tiles16(obase + d, acc);
+    // dQ[i][c] = sum_j dS^T[j][i] K[j][c]
+    load_kmajor16(xk, base + d, ld, r, g);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    contract_frames16(acc, xk, dst_);
+    store_tiles16(obase, acc);
+}
+
 static int attn_check(const void* a, const void* b, int64_t n_seq, int T, int d) {
     if (n_seq < 1 || d < HD || (d % HD) != 0) return VLG_ERR_SHAPE;
     if (T != 4 && T != 8 && T != 16 && T != 32) return VLG_ERR_SHAPE;
@@ -207,7 +373,8 @@ extern "C" int vlg_attention_fwd(const float* qkv, float* o, int64_t n_seq, int 
     switch (T) {
         case 4:  hipLaunchKernelGGL(attn_fwd_kernel<4>,  grid, block, 0, s, qkv, o, d, H); break;
         case 8:  hipLaunchKernelGGL(attn_fwd_kernel<8>,  grid, block, 0, s, qkv, o, d, H); break;
-        case 16: hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, block, 0, s, qkv, o, d, H); break;
+        case 16: hipLaunchKernelGGL(attn16_fwd_kernel, dim3((unsigned)((n_seq * H + 3) / 4)), dim3(256), 0, s, qkv, o, d,
+                                    H, n_seq * H); break;
         default: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, s, qkv, o, d, H); break;
     }
     return vlg_last_error();
@@ -223,7 +390,8 @@ extern "C" int vlg_attention_bwd(const float* qkv, const float* dout, float* dqk
     switch (T) {
         case 4:  hipLaunchKernelGGL(attn_bwd_kernel<4>,  grid, block, 0, s, qkv, dout, dqkv, d, H); break;
         case 8:  hipLaunchKernelGGL(attn_bwd_kernel<8>,  grid, block, 0, s, qkv, dout, dqkv, d, H); break;
-        case 16: hipLaunchKernelGGL(attn_bwd_kernel<16>, grid, block, 0, s, qkv, dout, dqkv, d, H); break;
+        case 16: hipLaunchKernelGGL(attn16_bwd_kernel, dim3((unsigned)((n_seq * H + 3) / 4)), dim3(256), 0, s, qkv, dout,
+                                    dqkv, d, H, n_seq * H); break;
         default: hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, 0, s, qkv, dout, dqkv, d, H); break;
     }
     return vlg_last_error();

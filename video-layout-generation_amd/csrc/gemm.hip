@@ -258,12 +258,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
 static unsigned long long* vlg_gemm_clock_probe = nullptr;
 extern "C" void vlg_debug_set_clock_probe(unsigned long long* p) { vlg_gemm_clock_probe = p; }
 
-// development switch for tools/kernel_bench.py A/B runs: VLG_GEMM_BK = 16 | 32 (contraction depth per tile)
-static int gemm_bk() {
+// Contraction depth per tile.  Measured on MI355X at the metric shape (tools/kernel_bench.py):
+// BK = 32 (2 blocks / CU) is 3-5 % faster for plain epilogues, BK = 16 (41 KB LDS, 4 blocks / CU)
+// is 8-11 % faster when the epilogue is heavy (GELU / dGELU: two extra 134 MB streams), because more
+// resident blocks de-synchronise the store bursts from the other blocks' MFMA phases.
+// VLG_GEMM_BK=16|32 forces one value for A/B runs.
+static int gemm_bk_override() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("VLG_GEMM_BK");
-        v = (e && atoi(e) == 16) ? 16 : 32;
+        v = e ? atoi(e) : 0;
     }
     return v;
 }
@@ -277,7 +281,9 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
     const dim3 grid((unsigned)blocks), block(GEMM_THREADS);
     g.clock_probe = vlg_gemm_clock_probe;
     if constexpr (BM == 128 && BN == 128) {
-        if (gemm_bk() == 16) {
+        const int forced = gemm_bk_override();
+        const bool heavy_epilogue = (EPI & (VLG_EPI_GELU | VLG_EPI_DGELU)) != 0;
+        if (forced == 16 || (forced != 32 && heavy_epilogue)) {
             hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, A_KC, B_KC, EPI, COLSUM>), grid, block, 0, s, g);
             return vlg_last_error();
         }

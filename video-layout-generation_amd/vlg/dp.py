@@ -40,8 +40,10 @@ def bucket_ranges(layout: "Dict[str, Tuple[int, Tuple[int, ...]]]", n_params: in
 class GradReducer:
     """Bucketed asynchronous all-reduce over one flat buffer."""
 
-    def __init__(self, flat: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None):
+    def __init__(self, flat: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None,
+                 always_communicate: bool = False):
         self.flat, self.group = flat, group
+        self.always = always_communicate      # run the collectives even at world size 1 (1-GPU RCCL rehearsal)
         self.buckets = {tag: (s, e) for tag, s, e in buckets}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.pending: list = []
@@ -61,7 +63,7 @@ class GradReducer:
 
     def ready(self, tag: str) -> None:
         """Called by backward when every gradient of bucket `tag` has been written (stream-ordered)."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         s, e = self.buckets[tag]
         self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
