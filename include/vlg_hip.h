@@ -147,6 +147,49 @@ int vlg_prep_input(const float* e1, const float* seg1, const float* frame1,
                    float* x10, float* frame3_out, int64_t* seg3_out,
                    int b, int H, int W, int flip, void* stream);
 
+/* ------------------------------------------------- GridNet convolution path (reference-real)
+ * The reference's trainable model (CoordGridNet / GridNet, reference src/models/gridnet.py:7-114) is built
+ * from three blocks (reference src/models/modules.py:5-58): PReLU -> conv3x3 -> PReLU -> conv3x3, the first
+ * conv stride 2 in down blocks, a bilinear x2 (align_corners=True) in front of up blocks.  These entry
+ * points replace nn.Conv2d(k=3, padding=1[, stride=2]) + nn.PReLU() + nn.Upsample at modules.py:12-17,
+ * 34-39, 49-55 and AddCoords at modules.py:65-96, forward and backward.
+ *
+ * Tensors are "padded NHWC": rows p = (n*(H+2) + y')*(W+2) + x' of Cp floats (Cp = channels rounded up to
+ * 32, extras zero), zero one-pixel halo, zero guard rows before/after (csrc/conv.hip header).  Weights are
+ * [cout_p][9][cin_p] (tap = ky*3+kx), bias [cout_p].  rowmask[p] = 1 on interior pixels, 0 on the halo.
+ * rowtab (stride 2 forward / weight gradient): output row -> input row of the window centre.
+ * tap_tables (stride 2 data gradient): [9][tab_stride] input row -> output row through that tap, or a
+ * guard row.  prelu_slope: device pointer to the single shared slope (NULL = no activation); the
+ * activation is applied to channels < act_ch only, so appended AddCoords channels stay linear. */
+#define VLG_CEPI_BIAS   1   /* (fwd always adds bias when bias != NULL)                          */
+#define VLG_CEPI_RESID  2   /* out += resid[row, col]   (sum with the other grid branch)         */
+#define VLG_CEPI_PRELU  4   /* out = prelu(out)         (activation applied by the producer)     */
+#define VLG_CEPI_DPRELU 8   /* dgrad: din = acc * prelu'(x_in); slope-gradient partials -> da    */
+#define VLG_CEPI_ACCUM  16  /* C += result              (tensor consumed by several blocks)      */
+int vlg_conv3x3_fwd(const float* in, const float* w, const float* bias, float* out, const float* resid,
+                    const float* rowmask, const float* prelu_slope, const int* rowtab, int64_t rows_out,
+                    int cin_p, int cout, int cout_p, int wp_in, int act_ch, int epilogue, void* stream);
+int vlg_conv3x3_dgrad_slabs(int64_t rows_in, int cin_p);   /* length of the slope-gradient partial vector */
+int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, const float* x_in,
+                      const float* rowmask_in, const float* prelu_slope, float* da_slab,
+                      const int* tap_tables, int64_t tab_stride, int64_t rows_in, int cin_p, int cout_p,
+                      int wp, int act_ch, int epilogue, void* stream);
+int vlg_conv3x3_wgrad_slabs(int64_t rows, int cin_p, int cout_p);
+int vlg_conv3x3_wgrad(const float* dout, const float* in, float* slabs, int64_t slab_stride,
+                      const int* rowtab, const float* prelu_slope, int64_t rows, int cin_p, int cout_p,
+                      int wp_in, int act_ch, void* stream);
+/* (b,C,H,W) <-> padded NHWC; to_padded can append AddCoords' two channels (modules.py:65-96) at c0, c0+1 */
+int vlg_nchw_to_padded(const float* src, float* dst, int b, int C, int H, int W, int cp, int coord_c0, void* stream);
+int vlg_padded_to_nchw(const float* src, float* dst, int b, int C, int H, int W, int cp, void* stream);
+int vlg_fill_coords(float* dst, int b, int H, int W, int cp, int coord_c0, void* stream);
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True), modules.py:50, on padded NHWC */
+int vlg_upsample2x_fwd(const float* in, float* out, int b, int h, int w, int cp, void* stream);
+int vlg_upsample2x_bwd(const float* dout, float* din, int b, int h, int w, int cp, int accumulate, void* stream);
+/* dst = src (+ dst): gradient hand-over along the residual sums of gridnet.py:51-56 */
+int vlg_add_rows(float* dst, const float* src, int64_t n, int accumulate, void* stream);
+/* sums a vector of per-block partials into dst[0] (PReLU slope gradients); accumulate != 0 adds to dst */
+int vlg_sum_partials(const float* partials, int n, float* dst, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,8 +16,15 @@ Sources of each fixture (reference file:line):
                             cat, shared flip) evaluated verbatim on small inputs; trainer.py itself cannot be
                             imported here (torchvision / tensorboardX / cv2 absent).
   average_meter.npz         utils.AverageMeter imported from reference src/utils.py:1-16.
-  gridnet_keys.json         state-dict key lists of models.GridNet(10) (reference src/models/gridnet.py:7-58),
-                            kept for checkpoint-format work on the conv path.
+  gridnet_keys.json         state-dict key lists of models.GridNet(10) (reference src/models/gridnet.py:7-58).
+  gridnet_small.npz         models.GridNet(10, filters_level=[8,16,24]) on a (2,10,32,48) input: seg, img, input
+                            gradient and EVERY parameter gradient under loss = sum(seg*r1) + sum(img*r2).
+  gridnet_full64.npz        models.GridNet(10) (real widths 32/64/96) on (1,10,64,64): outputs, dx, seven parameter
+                            gradients, all PReLU-slope gradients, |grad| sums of every tensor.
+  coordgridnet_256.npz      models.CoordGridNet(10, filters_level=[8,16,24]) on (1,10,256,256) (the only size the
+                            reference accepts): img, seg crop + checksums, dx crop, lateral_in / up_05 gradients.
+                            Parameters in all three come from oracle.gridnet_spec.test_params (name-seeded), so
+                            no weights are stored.
 """
 import json
 import os
@@ -101,6 +108,84 @@ def main():
         am.update(v, n)
         avgs.append(am.avg)
     np.savez_compressed(os.path.join(OUT, "average_meter.npz"), vals=np.array(vals), ns=np.array(ns), avgs=np.array(avgs))
+
+    # ---- GridNet / CoordGridNet: outputs and parameter gradients of the reference modules themselves,
+    # with parameters overwritten by oracle.gridnet_spec.test_params (so fixtures need not store weights)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import gridnet_spec as G
+
+    def run(model, shapes, x, seed, linear=False, want_margin=False):
+        params = G.test_params(shapes, seed=seed, linear=linear)
+        sd = model.state_dict()
+        assert list(sd.keys()) == list(shapes.keys()), (list(sd.keys())[:5], list(shapes.keys())[:5])
+        for k, v in params.items():
+            assert tuple(sd[k].shape) == tuple(v.shape), k
+        model.load_state_dict(params)
+        margin = [float("inf")]
+        hooks = []
+        if want_margin:     # smallest |pre-activation| entering any PReLU (see gridnet_spec.test_params docstring)
+            for m in model.modules():
+                if isinstance(m, nn.PReLU):
+                    hooks.append(m.register_forward_hook(lambda mod, inp, out: margin.__setitem__(0, min(margin[0], float(inp[0].detach().abs().min())))))
+        g = torch.Generator().manual_seed(seed + 77)
+        xin = x.clone().requires_grad_(True)
+        seg, img = model(xin)
+        for h in hooks:
+            h.remove()
+        r_seg, r_img = torch.randn(seg.shape, generator=g), torch.randn(img.shape, generator=g)
+        ((seg * r_seg).sum() + (img * r_img).sum()).backward()
+        grads = {k: v.grad.detach() for k, v in model.named_parameters()}
+        return seg.detach(), img.detach(), grads, xin.grad.detach(), r_seg, r_img, margin[0]
+
+    # A: small channels, non-square, batch 2: everything stored, with the real slopes and with slopes = 1
+    # (see oracle.gridnet_spec.test_params for why both exist)
+    filt = [8, 16, 24]
+    shapes = G.param_shapes(10, filt)
+    x = torch.randn(2, 10, 32, 48, generator=torch.Generator().manual_seed(3))
+    rec = {"x": x.numpy()}
+    for tag, linear in (("", False), ("lin_", True)):
+        seg, img, grads, dx, r_seg, r_img, margin = run(ref_models.GridNet(10, filters_level=filt), shapes, x, 1,
+                                                       linear=linear, want_margin=True)
+        rec.update({tag + "seg": seg.numpy(), tag + "img": img.numpy(), tag + "dx": dx.numpy(),
+                    tag + "kink_margin": np.float64(margin)})
+        rec.update({tag + "grad:" + k: v.numpy() for k, v in grads.items()})
+    rec.update(r_seg=r_seg.numpy(), r_img=r_img.numpy())
+    np.savez_compressed(os.path.join(OUT, "gridnet_small.npz"), **rec)
+
+    # B: the real channel widths [32,64,96] at 64x64, twice: real slopes (forward strict, gradients kink-tolerant)
+    # and slopes = 1 (everything strict)
+    shapes = G.param_shapes(10)
+    x = torch.randn(1, 10, 64, 64, generator=torch.Generator().manual_seed(4))
+    keep = ["lateral_in.conv.1.weight", "lateral_in.conv2.bias", "down_10.conv.1.weight", "lateral_23.conv.3.weight",
+            "up_05.up.2.weight", "lateral_out_img.conv.3.weight", "lateral_out_seg.conv.1.bias"]
+    rec = {}
+    for tag, linear in (("", False), ("lin_", True)):
+        seg, img, grads, dx, r_seg, r_img, _ = run(ref_models.GridNet(10), shapes, x, seed=2, linear=linear)
+        rec.update({tag + "seg": seg.numpy(), tag + "img": img.numpy(), tag + "dx": dx.numpy()})
+        rec.update({tag + "grad:" + k: grads[k].numpy() for k in keep})
+        rec[tag + "prelu_grads"] = np.array([float(v) for k, v in grads.items() if v.numel() == 1], dtype=np.float32)
+        rec[tag + "grad_abs_sums"] = np.array([float(v.abs().sum()) for v in grads.values()], dtype=np.float64)
+    rec["prelu_names"] = np.array([k for k, v in grads.items() if v.numel() == 1])
+    np.savez_compressed(os.path.join(OUT, "gridnet_full64.npz"), **rec)
+
+    # C: CoordGridNet (accepts 256x256 only: AddCoords buffers are hard-coded, modules.py:69-70; it also calls
+    # .cuda() in its constructor, so construct it with Tensor.cuda patched to a no-op - SURVEY.md section 8c)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    rec = {}
+    try:
+        shapes = G.param_shapes(10, filt, coord=True)
+        x = torch.randn(1, 10, 256, 256, generator=torch.Generator().manual_seed(5))
+        for tag, linear in (("", False), ("lin_", True)):
+            seg, img, grads, dx, r_seg, r_img, _ = run(ref_models.CoordGridNet(10, filters_level=filt), shapes, x, seed=3, linear=linear)
+            rec.update({tag + "seg_crop": seg[:, :, :24, :24].numpy(), tag + "img_crop": img[:, :, 100:164, 100:164].numpy(),
+                        tag + "seg_sum": np.float64(seg.double().sum()), tag + "seg_sq": np.float64((seg.double() ** 2).sum()),
+                        tag + "img_sum": np.float64(img.double().sum()), tag + "img_sq": np.float64((img.double() ** 2).sum()),
+                        tag + "dx_crop": dx[:, :, -16:, -16:].numpy()})
+            rec.update({tag + "grad:" + k: v.numpy() for k, v in grads.items() if k.startswith("lateral_in") or k.startswith("up_05")})
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    np.savez_compressed(os.path.join(OUT, "coordgridnet_256.npz"), **rec)
 
     torch.manual_seed(0)
     gn = ref_models.GridNet(10)

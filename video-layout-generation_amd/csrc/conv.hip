@@ -1,0 +1,373 @@
+// 3x3 convolutions of the reference's GridNet (reference src/models/modules.py:5-58) as fp32 MFMA
+// implicit GEMMs - forward, data gradient and weight gradient - on halo-padded channels-last tensors.
+//
+// Activation format ("padded NHWC"): a (b, C, H, W) tensor is stored as rows p = (n*(H+2) + y')*(W+2) + x'
+// of Cp floats (C padded to a multiple of 32, extra channels zero), with a ZERO one-pixel halo and a zero
+// guard band of rows before and after.  Then tap (ky,kx) of a stride-1 3x3 convolution is just a constant
+// ROW SHIFT (ky-1)*(W+2) + (kx-1) of the same matrix:
+//     out[p, co] = mask[p] * ( bias[co] + sum_tap sum_ci act(in[p + shift(tap), ci]) * W[co][tap][ci] )
+// i.e. a GEMM with M = rows, N = Cout, K = 9*Cp whose A-operand base pointer moves once per K tile (Cp is
+// a multiple of BK = 32, so a K tile never straddles taps).  No im2col buffer, no boundary branches: the
+// halo supplies the zero padding and the epilogue multiplies halo rows by mask = 0 so the halo stays zero.
+// Stride-2 (down-sampling) convolutions use one int row table (output row -> input row of the window
+// centre); their data gradient uses nine per-tap tables that point at a guard (zero) row where a tap does
+// not exist.  Weights live as [Cout][9][Cp] so forward reads them K-contiguous, the data gradient reads
+// them contraction-major with a per-tap column offset, and the weight gradient writes that layout directly.
+// PReLU (single shared slope, nn.PReLU() default) is applied to the gathered operand on its way to LDS
+// (forward: A; weight gradient: B); its derivative and the slope gradient are fused into the data
+// gradient's epilogue.  The MFMA tile machinery (fragment layouts, LDS staging, mid-tile pipeline) is the
+// one of gemm.hip (gemm_tile.h).
+#include "gemm_tile.h"
+#include <type_traits>
+
+#define CONV_FWD 0
+#define CONV_DGRAD 1
+#define CONV_WGRAD 2
+
+struct ConvArgs {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* aux_in; const float* rowmask; const float* prelu; float* da_slab;
+    const int* rowtab; int64_t tab_stride;
+    int64_t M;               // rows of C
+    int N;                   // cols of C that are stored
+    int64_t Kc;              // contraction extent
+    int lda, ldb, ldc;
+    int cin;                 // channels per tap of the gathered operand (multiple of 32)
+    int b_tap_stride;        // dgrad: column offset of one tap inside a weight row
+    int shift[9];
+    int tiles_m, tiles_n, splits;
+    int64_t kc_per_split, slab_stride, colsum_off;
+    int epi;
+    int act_ch;              // PReLU applies to channels < act_ch only (AddCoords channels stay linear)
+};
+
+__device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
+// channels c .. c+3 of one pixel; channels >= act_ch (the AddCoords pair) are left linear
+__device__ __forceinline__ float4 prelu4(float4 v, float a, int c, int act_ch) {
+    return make_float4(c < act_ch ? prelu_f(v.x, a) : v.x, c + 1 < act_ch ? prelu_f(v.y, a) : v.y,
+                       c + 2 < act_ch ? prelu_f(v.z, a) : v.z, c + 3 < act_ch ? prelu_f(v.w, a) : v.w);
+}
+
+template <int MODE, int BM, int BN>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvArgs g) {
+    constexpr int BK = 32;
+    constexpr bool A_KC = MODE != CONV_WGRAD;
+    constexpr bool B_KC = MODE == CONV_FWD;
+    constexpr int WM = (BM == 32) ? 1 : ((BN == 128 || BN == 64) ? 2 : 4);
+    constexpr int WN = 4 / WM;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    static_assert(TM >= 1 && TN >= 1 && TM * 32 * WM == BM && TN * 32 * WN == BN, "tile / wave layout");
+    using TA = Tile<BM, A_KC, BK>;
+    using TB = Tile<BN, B_KC, BK>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::FLOATS + TB::FLOATS)];
+    __shared__ float red[GEMM_THREADS / 64];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * TA::FLOATS;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int split = swz / ntile;
+    const int tile = swz - split * ntile;
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const int64_t kbeg = (int64_t)split * g.kc_per_split;
+    int64_t kend = kbeg + g.kc_per_split;
+    if (kend > g.Kc) kend = g.Kc;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const float slope = g.prelu ? g.prelu[0] : 1.0f;          // slope 1 == identity
+    const bool act_on_load = g.prelu != nullptr && MODE != CONV_DGRAD;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float colacc = 0.f;
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + l31;
+        bv[j] = (MODE == CONV_FWD && g.bias != nullptr) ? g.bias[col < g.N ? col : g.N - 1] : 0.f;
+    }
+
+    // ---- per-thread constants of the gathers
+    // forward / data gradient: the rows of A this thread stages (fixed across K tiles)
+    int64_t arow[TA::NV];
+    if constexpr (MODE != CONV_WGRAD) {
+#pragma unroll
+        for (int i = 0; i < TA::NV; ++i) {
+            int64_t r = m0 + ((tid + GEMM_THREADS * i) >> 3);
+            arow[i] = r < g.M ? r : g.M - 1;                   // rows past M are computed but never stored
+        }
+        if (g.rowtab != nullptr && g.tab_stride == 0) {
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) arow[i] = g.rowtab[arow[i]];
+        }
+    }
+    // weight gradient: the (tap, channel) of every B column this thread stages
+    int64_t bcoloff[TB::NV];
+    int bch[TB::NV];
+    if constexpr (MODE == CONV_WGRAD) {
+#pragma unroll
+        for (int i = 0; i < TB::NV; ++i) {
+            int col = n0 + (((tid + GEMM_THREADS * i) % (BN / 4)) << 2);
+            if (col > g.N - 4) col = g.N - 4;                  // columns past N are computed but never stored
+            const int tap = col / g.cin;
+            bcoloff[i] = (int64_t)g.shift[tap] * g.ldb + (col - tap * g.cin);
+            bch[i] = col - tap * g.cin;
+        }
+    }
+
+    float4 ra[TA::NV], rb[TB::NV];
+    int ach = 0;                                              // first channel of this thread's float4 in the staged A tile
+    auto gload = [&](int64_t k0) {
+        if constexpr (MODE != CONV_WGRAD) {
+            const int tap = (int)(k0 / g.cin);
+            const int ci0 = (int)(k0 - (int64_t)tap * g.cin);
+            const int64_t sh = g.shift[tap];
+            ach = ci0 + ((tid & 7) << 2);
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) {
+                int64_t r = arow[i];
+                if (g.tab_stride != 0) r = g.rowtab[(int64_t)tap * g.tab_stride + r];
+                ra[i] = ld4(g.A + (r + sh) * g.lda + ci0 + (((tid + GEMM_THREADS * i) & 7) << 2));
+            }
+            if constexpr (MODE == CONV_FWD) {
+#pragma unroll
+                for (int i = 0; i < TB::NV; ++i) {
+                    const int idx = tid + GEMM_THREADS * i;
+                    if (TB::F4 % GEMM_THREADS != 0 && idx >= TB::F4) { rb[i] = f4_zero(); continue; }
+                    int row = n0 + (idx >> 3);
+                    row = row < g.N ? row : g.N - 1;
+                    rb[i] = ld4(g.B + (int64_t)row * g.ldb + k0 + ((idx & 7) << 2));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TB::NV; ++i) {
+                    const int idx = tid + GEMM_THREADS * i;
+                    if (TB::F4 % GEMM_THREADS != 0 && idx >= TB::F4) { rb[i] = f4_zero(); continue; }
+                    const int co = ci0 + idx / (BN / 4);
+                    rb[i] = ld4(g.B + (int64_t)co * g.ldb + (int64_t)tap * g.b_tap_stride + n0 + ((idx % (BN / 4)) << 2));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) {
+                const int idx = tid + GEMM_THREADS * i;
+                if (TA::F4 % GEMM_THREADS != 0 && idx >= TA::F4) { ra[i] = f4_zero(); continue; }
+                ra[i] = ld4(g.A + (k0 + idx / (BM / 4)) * g.lda + m0 + ((idx % (BM / 4)) << 2));
+            }
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) {
+                int64_t kr = k0 + (tid + GEMM_THREADS * i) / (BN / 4);
+                if (g.rowtab != nullptr) kr = g.rowtab[kr];
+                rb[i] = ld4(g.B + kr * g.ldb + bcoloff[i]);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+        if (act_on_load) {
+            if constexpr (MODE == CONV_FWD) {
+#pragma unroll
+                for (int i = 0; i < TA::NV; ++i) ra[i] = prelu4(ra[i], slope, ach, g.act_ch);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TB::NV; ++i) rb[i] = prelu4(rb[i], slope, bch[i], g.act_ch);
+            }
+        }
+        TA::sstore(ra, As0 + buf * TA::FLOATS, tid);
+        TB::sstore(rb, Bs0 + buf * TB::FLOATS, tid);
+    };
+    auto chunk = [&](const float* as, const float* bs, int s) {
+        float a[TM][4], b[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) TA::frag(a[i], as, (wm * TM + i) * 32 + l31, s, h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) TB::frag(b[j], bs, (wn * TN + j) * 32 + l31, s, h);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+    };
+
+    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+    if (nk > 0) { gload(kbeg); sstore(0); }
+    if (nk > 1) gload(kbeg + BK);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const float* as = As0 + cur * TA::FLOATS;
+        const float* bs = Bs0 + cur * TB::FLOATS;
+        chunk(as, bs, 0);
+        chunk(as, bs, 1);
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        if (kt + 2 < nk) gload(kbeg + (int64_t)(kt + 2) * BK);
+        chunk(as, bs, 2);
+        chunk(as, bs, 3);
+        if constexpr (MODE == CONV_WGRAD) {
+            if (tn == 0 && tid < BM) {                          // bias gradient: column sums of the dOut tile
+#pragma unroll 8
+                for (int kk = 0; kk < BK; ++kk) colacc += as[kk * BM + tid];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h)
+    float* Cs = g.C + (int64_t)split * g.slab_stride;
+    const int64_t row0 = m0 + wm * TM * 32 + 4 * h;
+    const int col0 = n0 + wn * TN * 32 + l31;
+    float da = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + j * 32;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row >= g.M) continue;
+                const int64_t o = row * g.ldc + col;
+                float v = acc[i][j][r] + bv[j];
+                if constexpr (MODE != CONV_WGRAD) {
+                    if (g.epi & VLG_CEPI_RESID) v += g.aux_in[o];
+                    if (g.epi & VLG_CEPI_PRELU) v = prelu_f(v, slope);
+                    if (g.rowmask != nullptr) v *= g.rowmask[row];
+                    if (g.epi & VLG_CEPI_DPRELU) {
+                        const float x = g.aux_in[o];
+                        if (col < g.act_ch) {
+                            da += x > 0.f ? 0.f : v * x;
+                            v *= x > 0.f ? 1.0f : slope;
+                        }
+                    }
+                    if (g.epi & VLG_CEPI_ACCUM) v += Cs[o];
+                }
+                Cs[o] = v;
+            }
+        }
+    if constexpr (MODE == CONV_WGRAD) {
+        if (tn == 0 && tid < BM && m0 + tid < g.M) Cs[g.colsum_off + m0 + tid] = colacc;
+    }
+    if constexpr (MODE == CONV_DGRAD) {
+        if (g.da_slab != nullptr) {                             // slope gradient: one partial per block
+            da = block_sum(da, red);
+            if (tid == 0) g.da_slab[bid] = da;
+        }
+    }
+}
+
+template <int MODE, int BM, int BN>
+static int launch_conv(ConvArgs g, hipStream_t s) {
+    g.tiles_m = (int)((g.M + BM - 1) / BM);
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+    if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN>), dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, s, g);
+    return vlg_last_error();
+}
+
+static void fill_shifts(ConvArgs& g, int wp, int sign) {
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g.shift[ky * 3 + kx] = sign * ((ky - 1) * wp + (kx - 1));
+}
+
+static bool conv_ok(const void* p) { return p != nullptr && vlg_aligned16(p); }
+
+extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bias, float* out, const float* resid,
+                               const float* rowmask, const float* prelu_slope, const int* rowtab, int64_t rows_out,
+                               int cin_p, int cout, int cout_p, int wp_in, int act_ch, int epilogue, void* stream) {
+    if (rows_out < 1 || cin_p < 32 || (cin_p & 31) || cout < 1 || cout > cout_p || (cout_p & 31) || cout_p > 128)
+        return VLG_ERR_SHAPE;
+    if (!conv_ok(in) || !conv_ok(w) || !conv_ok(out)) return VLG_ERR_ALIGN;
+    if ((epilogue & VLG_CEPI_RESID) && !resid) return VLG_ERR_SHAPE;
+    ConvArgs g{};
+    g.A = in; g.B = w; g.C = out; g.bias = bias; g.aux_in = resid; g.rowmask = rowmask; g.prelu = prelu_slope;
+    g.rowtab = rowtab; g.tab_stride = 0;
+    g.M = rows_out; g.N = cout; g.Kc = 9 * (int64_t)cin_p;
+    g.lda = cin_p; g.ldb = 9 * cin_p; g.ldc = cout_p; g.cin = cin_p;
+    g.splits = 1; g.kc_per_split = g.Kc; g.epi = epilogue & ~VLG_CEPI_DPRELU; g.act_ch = act_ch;
+    fill_shifts(g, wp_in, rowtab ? 1 : 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (cout_p == 32) return launch_conv<CONV_FWD, 128, 32>(g, s);
+    if (cout_p == 64) return launch_conv<CONV_FWD, 128, 64>(g, s);
+    if (cout_p == 96) return launch_conv<CONV_FWD, 128, 96>(g, s);
+    return launch_conv<CONV_FWD, 128, 128>(g, s);
+}
+
+extern "C" int vlg_conv3x3_dgrad_slabs(int64_t rows_in, int cin_p) {
+    const int bn = cin_p;                                   // one column tile (cin_p <= 128)
+    return (int)((rows_in + 127) / 128) * ((cin_p + bn - 1) / bn);
+}
+
+extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, const float* x_in,
+                                 const float* rowmask_in, const float* prelu_slope, float* da_slab,
+                                 const int* tap_tables, int64_t tab_stride, int64_t rows_in, int cin_p, int cout_p,
+                                 int wp, int act_ch, int epilogue, void* stream) {
+    // din[p, ci] = mask[p] * sum_tap sum_co dout[p - shift(tap), co] * W[co][tap][ci]   (stride 1)
+    // stride 2: tap_tables[tap][p] = output row feeding input row p through that tap (or a zero guard row)
+    if (rows_in < 1 || cin_p < 32 || (cin_p & 31) || cin_p > 128 || cout_p < 32 || (cout_p & 31)) return VLG_ERR_SHAPE;
+    if (!conv_ok(dout) || !conv_ok(w) || !conv_ok(din)) return VLG_ERR_ALIGN;
+    if ((epilogue & VLG_CEPI_DPRELU) && (!x_in || !prelu_slope)) return VLG_ERR_SHAPE;
+    ConvArgs g{};
+    g.A = dout; g.B = w; g.C = din; g.aux_in = x_in; g.rowmask = rowmask_in; g.prelu = prelu_slope; g.da_slab = da_slab;
+    g.rowtab = tap_tables; g.tab_stride = tap_tables ? tab_stride : 0;
+    g.M = rows_in; g.N = cin_p; g.Kc = 9 * (int64_t)cout_p;
+    g.lda = cout_p; g.ldb = 9 * cin_p; g.ldc = cin_p; g.cin = cout_p; g.b_tap_stride = cin_p;
+    g.splits = 1; g.kc_per_split = g.Kc; g.epi = epilogue & (VLG_CEPI_DPRELU | VLG_CEPI_ACCUM); g.act_ch = act_ch;
+    if (tap_tables) { for (int t = 0; t < 9; ++t) g.shift[t] = 0; }
+    else fill_shifts(g, wp, -1);
+    hipStream_t s = (hipStream_t)stream;
+    if (cin_p == 32) return launch_conv<CONV_DGRAD, 128, 32>(g, s);
+    if (cin_p == 64) return launch_conv<CONV_DGRAD, 128, 64>(g, s);
+    if (cin_p == 96) return launch_conv<CONV_DGRAD, 128, 96>(g, s);
+    return launch_conv<CONV_DGRAD, 128, 128>(g, s);
+}
+
+static void conv_wgrad_plan(int64_t rows, int cin_p, int cout_p, int* splits, int64_t* per) {
+    const int64_t tiles = (cout_p / 32) * (int64_t)((9 * cin_p + 127) / 128);
+    int64_t want = 512 / tiles;
+    const int64_t max_splits = (rows + 255) / 256;
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    int64_t p = (rows + want - 1) / want;
+    p = (p + 31) / 32 * 32;
+    *per = p;
+    *splits = (int)((rows + p - 1) / p);
+}
+
+extern "C" int vlg_conv3x3_wgrad_slabs(int64_t rows, int cin_p, int cout_p) {
+    int splits; int64_t per;
+    conv_wgrad_plan(rows, cin_p, cout_p, &splits, &per);
+    return splits;
+}
+
+extern "C" int vlg_conv3x3_wgrad(const float* dout, const float* in, float* slabs, int64_t slab_stride,
+                                 const int* rowtab, const float* prelu_slope, int64_t rows, int cin_p, int cout_p,
+                                 int wp_in, int act_ch, void* stream) {
+    // slab[s][co*(9*cin_p) + tap*cin_p + ci] = sum_{p in split s} dout[p, co] * act(in[row(p) + shift(tap), ci])
+    // slab[s][cout_p*9*cin_p + co]           = sum_p dout[p, co]                (bias gradient)
+    // rows past `rows` are read from the zero guard band (dout there is zero), so no edge handling is needed
+    if (rows < 1 || cin_p < 32 || (cin_p & 31) || cout_p < 32 || (cout_p & 31)) return VLG_ERR_SHAPE;
+    if (slab_stride < (int64_t)cout_p * 9 * cin_p + cout_p) return VLG_ERR_SHAPE;
+    if (!conv_ok(dout) || !conv_ok(in) || !conv_ok(slabs)) return VLG_ERR_ALIGN;
+    ConvArgs g{};
+    g.A = dout; g.B = in; g.C = slabs; g.prelu = prelu_slope; g.rowtab = rowtab;
+    g.M = cout_p; g.N = 9 * cin_p; g.Kc = rows;
+    g.lda = cout_p; g.ldb = cin_p; g.ldc = 9 * cin_p; g.cin = cin_p;
+    conv_wgrad_plan(rows, cin_p, cout_p, &g.splits, &g.kc_per_split);
+    g.slab_stride = slab_stride; g.colsum_off = (int64_t)cout_p * 9 * cin_p; g.act_ch = act_ch;
+    fill_shifts(g, wp_in, 1);
+    return launch_conv<CONV_WGRAD, 32, 128>(g, (hipStream_t)stream);
+}

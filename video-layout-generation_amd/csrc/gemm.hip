@@ -25,9 +25,7 @@
 #include <type_traits>
 #include <stdlib.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define GEMM_THREADS 256
+#include "gemm_tile.h"
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -39,60 +37,6 @@ struct GemmArgs {
     int tiles_m, tiles_n, splits;
     int64_t kc_per_split, slab_stride, colsum_off;
     unsigned long long* clock_probe;   // diagnostic only (VLG_GEMM_CLOCK_PROBE): {shader ticks, 100 MHz ticks} per block
-};
-
-// One operand tile: BR rows (non-contraction) x BK contraction steps.
-template <int BR, bool KC, int BK>
-struct Tile {
-    static constexpr int LDK = BK + 4;                                  // padded row stride of a KC tile
-    static constexpr int F4 = BR * BK / 4;                              // float4 per tile
-    static constexpr int NV = (F4 + GEMM_THREADS - 1) / GEMM_THREADS;   // float4 per thread
-    static constexpr int FLOATS = KC ? BR * LDK : BK * BR;
-    static constexpr int PER_ROW = KC ? BK / 4 : BR / 4;                // float4 per memory row
-
-    // GUARD = false: interior tile, plain loads that stay in flight until the LDS write.
-    // GUARD = true : edge tile; address clamped into the operand and the value zeroed by a select
-    //                (no branches).  Requires R >= 4 and kend - k0 >= 4 when anything is in range.
-    template <bool GUARD>
-    __device__ static __forceinline__ void gload(float4 (&r)[NV], const float* __restrict__ P, int ld,
-                                                 int64_t r0, int64_t R, int64_t k0, int64_t kend, int tid) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + GEMM_THREADS * i;
-            if (F4 % GEMM_THREADS != 0 && idx >= F4) { r[i] = f4_zero(); continue; }
-            const int major = idx / PER_ROW, minor = (idx % PER_ROW) << 2;
-            // KC: memory row = operand row, column = k.   MC: memory row = k, column = operand row.
-            const int64_t grow = KC ? r0 + major : k0 + major;
-            const int64_t gcol = KC ? k0 + minor : r0 + minor;
-            const int64_t rlim = KC ? R : kend, clim = KC ? kend : R;
-            if constexpr (GUARD) {
-                const bool ok = grow < rlim && gcol < clim;
-                const float4 v = ld4(P + (grow < rlim ? grow : rlim - 1) * ld + (gcol < clim ? gcol : clim - 4));
-                r[i] = ok ? v : f4_zero();
-            } else {
-                r[i] = ld4(P + grow * ld + gcol);
-            }
-        }
-    }
-    __device__ static __forceinline__ void sstore(const float4 (&r)[NV], float* S, int tid) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + GEMM_THREADS * i;
-            if (F4 % GEMM_THREADS != 0 && idx >= F4) continue;
-            if constexpr (KC) st4(S + (idx / PER_ROW) * LDK + ((idx % PER_ROW) << 2), r[i]);
-            else st4(S + (idx << 2), r[i]);
-        }
-    }
-    // 4 fragment values of tile row `row` for chunk s, lane half h:  k = 8s + 4h + j
-    __device__ static __forceinline__ void frag(float (&f)[4], const float* S, int row, int s, int h) {
-        if constexpr (KC) {
-            const float4 t = ld4(S + row * LDK + 8 * s + 4 * h);
-            f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) f[j] = S[(8 * s + 4 * h + j) * BR + row];
-        }
-    }
 };
 
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM>

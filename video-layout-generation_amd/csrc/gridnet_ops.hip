@@ -1,0 +1,193 @@
+// Layout and resampling kernels around the GridNet convolutions (all HBM-bound, one pass each).
+//   vlg_nchw_to_padded / vlg_padded_to_nchw   (b,C,H,W) <-> halo-padded channels-last (conv.hip header)
+//   vlg_fill_coords                           AddCoords channels          reference src/models/modules.py:65-96
+//   vlg_upsample2x_fwd / _bwd                 nn.Upsample(x2, bilinear, align_corners=True)  modules.py:50
+//   vlg_sum_partials                          per-block partial sums -> one scalar (PReLU slope gradients)
+#include "common.h"
+
+#define GO_BLOCK 256
+
+static unsigned go_blocks(int64_t n) {
+    int64_t b = (n + GO_BLOCK - 1) / GO_BLOCK;
+    return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// thread per (interior pixel, channel): reads NCHW (coalesced over x for fixed c), writes channels-last
+__global__ __launch_bounds__(GO_BLOCK) void nchw_to_padded_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                  int b, int C, int H, int W, int cp) {
+    const int64_t total = (int64_t)b * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GO_BLOCK) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int c = (int)((i / ((int64_t)W * H)) % C);
+        const int64_t n = i / ((int64_t)W * H * C);
+        dst[((n * (H + 2) + y + 1) * (W + 2) + x + 1) * cp + c] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(GO_BLOCK) void padded_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                  int b, int C, int H, int W, int cp) {
+    const int64_t total = (int64_t)b * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GO_BLOCK) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int c = (int)((i / ((int64_t)W * H)) % C);
+        const int64_t n = i / ((int64_t)W * H * C);
+        dst[i] = src[((n * (H + 2) + y + 1) * (W + 2) + x + 1) * cp + c];
+    }
+}
+
+// AddCoords: channel c0 varies along H, channel c0+1 along W, values k/(dim-1)*2 - 1
+// (reference modules.py:69-70 hard-codes 256; SURVEY.md section 8 a4 verified the orientation numerically)
+__global__ __launch_bounds__(GO_BLOCK) void fill_coords_kernel(float* __restrict__ dst, int b, int H, int W, int cp, int c0) {
+    const int64_t total = (int64_t)b * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GO_BLOCK) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int64_t n = i / ((int64_t)W * H);
+        float* px = dst + ((n * (H + 2) + y + 1) * (W + 2) + x + 1) * cp;
+        px[c0] = (float)y / (float)(H - 1) * 2.0f - 1.0f;
+        px[c0 + 1] = (float)x / (float)(W - 1) * 2.0f - 1.0f;
+    }
+}
+
+// align_corners=True source coordinate: src = dst * (in-1)/(out-1)  (ATen area_pixel_compute_scale)
+__device__ __forceinline__ void up_src(int o, int in, float scale, int& i0, int& i1, float& l1) {
+    const float s = scale * (float)o;
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+// thread per (output pixel, float4 of channels)
+__global__ __launch_bounds__(GO_BLOCK) void upsample2x_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                  int b, int h, int w, int cp) {
+    const int H = 2 * h, W = 2 * w, c4n = cp >> 2;
+    const float sh = (float)(h - 1) / (float)(H - 1), sw = (float)(w - 1) / (float)(W - 1);
+    const int64_t total = (int64_t)b * H * W * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GO_BLOCK) {
+        const int c = (int)(i % c4n) << 2;
+        const int X = (int)((i / c4n) % W);
+        const int Y = (int)((i / ((int64_t)c4n * W)) % H);
+        const int64_t n = i / ((int64_t)c4n * W * H);
+        int y0, y1, x0, x1; float ly, lx;
+        up_src(Y, h, sh, y0, y1, ly);
+        up_src(X, w, sw, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* base = in + (n * (h + 2)) * (int64_t)(w + 2) * cp + c;
+        const float4 a = ld4(base + ((int64_t)(y0 + 1) * (w + 2) + x0 + 1) * cp), bq = ld4(base + ((int64_t)(y0 + 1) * (w + 2) + x1 + 1) * cp);
+        const float4 cq = ld4(base + ((int64_t)(y1 + 1) * (w + 2) + x0 + 1) * cp), d = ld4(base + ((int64_t)(y1 + 1) * (w + 2) + x1 + 1) * cp);
+        float4 o;
+        o.x = hy * (hx * a.x + lx * bq.x) + ly * (hx * cq.x + lx * d.x);
+        o.y = hy * (hx * a.y + lx * bq.y) + ly * (hx * cq.y + lx * d.y);
+        o.z = hy * (hx * a.z + lx * bq.z) + ly * (hx * cq.z + lx * d.z);
+        o.w = hy * (hx * a.w + lx * bq.w) + ly * (hx * cq.w + lx * d.w);
+        st4(out + ((n * (H + 2) + Y + 1) * (int64_t)(W + 2) + X + 1) * cp + c, o);
+    }
+}
+
+// gather form of the transpose: every input pixel collects the output pixels whose 2x2 stencil touches it
+// (at most 3 output rows x 3 output columns around 2y, 2x), recomputing their weights - no atomics.
+__global__ __launch_bounds__(GO_BLOCK) void upsample2x_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                                  int b, int h, int w, int cp, int accumulate) {
+    const int H = 2 * h, W = 2 * w, c4n = cp >> 2;
+    const float sh = (float)(h - 1) / (float)(H - 1), sw = (float)(w - 1) / (float)(W - 1);
+    const int64_t total = (int64_t)b * h * w * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GO_BLOCK) {
+        const int c = (int)(i % c4n) << 2;
+        const int x = (int)((i / c4n) % w);
+        const int y = (int)((i / ((int64_t)c4n * w)) % h);
+        const int64_t n = i / ((int64_t)c4n * w * h);
+        float4 acc = f4_zero();
+        const float* base = dout + (n * (H + 2)) * (int64_t)(W + 2) * cp + c;
+        for (int Y = 2 * y - 2; Y <= 2 * y + 3; ++Y) {
+            if (Y < 0 || Y >= H) continue;
+            int y0, y1; float ly;
+            up_src(Y, h, sh, y0, y1, ly);
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int X = 2 * x - 2; X <= 2 * x + 3; ++X) {
+                if (X < 0 || X >= W) continue;
+                int x0, x1; float lx;
+                up_src(X, w, sw, x0, x1, lx);
+                const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+                if (wx == 0.f) continue;
+                const float4 g = ld4(base + ((int64_t)(Y + 1) * (W + 2) + X + 1) * cp);
+                const float wgt = wy * wx;
+                acc.x += wgt * g.x; acc.y += wgt * g.y; acc.z += wgt * g.z; acc.w += wgt * g.w;
+            }
+        }
+        float* dst = din + ((n * (h + 2) + y + 1) * (int64_t)(w + 2) + x + 1) * cp + c;
+        if (accumulate) acc = f4_add(acc, ld4(dst));
+        st4(dst, acc);
+    }
+}
+
+__global__ __launch_bounds__(GO_BLOCK) void sum_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ dst,
+                                                                int accumulate) {
+    __shared__ float red[GO_BLOCK / 64];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += GO_BLOCK) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) dst[0] = accumulate ? dst[0] + s : s;
+}
+
+__global__ __launch_bounds__(GO_BLOCK) void add_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n4,
+                                                           int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * GO_BLOCK) {
+        float4 v = ld4(src + 4 * i);
+        if (accumulate) v = f4_add(v, ld4(dst + 4 * i));
+        st4(dst + 4 * i, v);
+    }
+}
+
+extern "C" int vlg_add_rows(float* dst, const float* src, int64_t n, int accumulate, void* stream) {
+    if (n < 4 || (n & 3)) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(dst) || !vlg_aligned16(src)) return VLG_ERR_ALIGN;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(go_blocks(n / 4)), dim3(GO_BLOCK), 0, (hipStream_t)stream, dst, src, n / 4, accumulate);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_nchw_to_padded(const float* src, float* dst, int b, int C, int H, int W, int cp, int coord_c0, void* stream) {
+    if (b < 1 || C < 1 || H < 2 || W < 2 || cp < C || (cp & 3)) return VLG_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(nchw_to_padded_kernel, dim3(go_blocks((int64_t)b * C * H * W)), dim3(GO_BLOCK), 0, s, src, dst, b, C, H, W, cp);
+    if (coord_c0 >= 0) {
+        if (coord_c0 + 2 > cp) return VLG_ERR_SHAPE;
+        hipLaunchKernelGGL(fill_coords_kernel, dim3(go_blocks((int64_t)b * H * W)), dim3(GO_BLOCK), 0, s, dst, b, H, W, cp, coord_c0);
+    }
+    return vlg_last_error();
+}
+
+extern "C" int vlg_padded_to_nchw(const float* src, float* dst, int b, int C, int H, int W, int cp, void* stream) {
+    if (b < 1 || C < 1 || H < 1 || W < 1 || cp < C) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL(padded_to_nchw_kernel, dim3(go_blocks((int64_t)b * C * H * W)), dim3(GO_BLOCK), 0, (hipStream_t)stream, src, dst, b, C, H, W, cp);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_fill_coords(float* dst, int b, int H, int W, int cp, int coord_c0, void* stream) {
+    if (b < 1 || H < 2 || W < 2 || coord_c0 < 0 || coord_c0 + 2 > cp) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL(fill_coords_kernel, dim3(go_blocks((int64_t)b * H * W)), dim3(GO_BLOCK), 0, (hipStream_t)stream, dst, b, H, W, cp, coord_c0);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_upsample2x_fwd(const float* in, float* out, int b, int h, int w, int cp, void* stream) {
+    if (b < 1 || h < 2 || w < 2 || (cp & 3)) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(in) || !vlg_aligned16(out)) return VLG_ERR_ALIGN;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(go_blocks((int64_t)b * 4 * h * w * (cp / 4))), dim3(GO_BLOCK), 0, (hipStream_t)stream, in, out, b, h, w, cp);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_upsample2x_bwd(const float* dout, float* din, int b, int h, int w, int cp, int accumulate, void* stream) {
+    if (b < 1 || h < 2 || w < 2 || (cp & 3)) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(dout) || !vlg_aligned16(din)) return VLG_ERR_ALIGN;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(go_blocks((int64_t)b * h * w * (cp / 4))), dim3(GO_BLOCK), 0, (hipStream_t)stream, dout, din, b, h, w, cp, accumulate);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_sum_partials(const float* partials, int n, float* dst, int accumulate, void* stream) {
+    if (n < 1) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(GO_BLOCK), 0, (hipStream_t)stream, partials, n, dst, accumulate);
+    return vlg_last_error();
+}

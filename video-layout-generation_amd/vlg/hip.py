@@ -43,7 +43,20 @@ SIGNATURES = {
     "vlg_gradient_loss": (I, [P, P, P, P, P, I, I, I, F, P]),
     "vlg_ssim_loss": (I, [P, P, P, P, P, I, I, I, I, F, P]),
     "vlg_prep_input": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "vlg_conv3x3_fwd": (I, [P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, P]),
+    "vlg_conv3x3_dgrad_slabs": (I, [L, I]),
+    "vlg_conv3x3_dgrad": (I, [P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, P]),
+    "vlg_conv3x3_wgrad_slabs": (I, [L, I, I]),
+    "vlg_conv3x3_wgrad": (I, [P, P, P, L, P, P, L, I, I, I, I, P]),
+    "vlg_nchw_to_padded": (I, [P, P, I, I, I, I, I, I, P]),
+    "vlg_padded_to_nchw": (I, [P, P, I, I, I, I, I, P]),
+    "vlg_fill_coords": (I, [P, I, I, I, I, I, P]),
+    "vlg_upsample2x_fwd": (I, [P, P, I, I, I, I, P]),
+    "vlg_upsample2x_bwd": (I, [P, P, I, I, I, I, I, P]),
+    "vlg_add_rows": (I, [P, P, L, I, P]),
+    "vlg_sum_partials": (I, [P, I, P, I, P]),
 }
+CEPI_BIAS, CEPI_RESID, CEPI_PRELU, CEPI_DPRELU, CEPI_ACCUM = 1, 2, 4, 8, 16
 
 _lib = None
 
