@@ -141,6 +141,10 @@ int vlg_gradient_loss(const float* a, const float* b, float* da, float* loss, fl
                       int planes, int H, int W, float grad_scale, void* stream);
 int vlg_ssim_loss(const float* x, const float* y, float* dx, float* loss, float* scratch,
                   int b, int C, int H, int W, float grad_scale, void* stream);
+/* dst = (src - shift[c]) * scale[c] on (b,C,H,W), C <= 4; shift/scale are HOST arrays of C floats.
+ * img = (img - mean_arr) / std_arr, reference src/trainer.py:120-121,212 (and its transpose in backward). */
+int vlg_affine_nchw(const float* src, float* dst, int b, int C, int64_t hw, const float* shift_host,
+                    const float* scale_host, void* stream);
 int vlg_prep_input(const float* e1, const float* seg1, const float* frame1,
                    const float* frame2, const float* seg2, const float* e2,
                    const float* frame3, const int64_t* seg3,

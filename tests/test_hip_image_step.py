@@ -1,0 +1,45 @@
+"""GPU: the reference's own training-step body (reference src/trainer.py:193-258, SURVEY.md Appendix-A repairs,
+HED edges as inputs, VGG term omitted) on the HIP kernels vs its CPU restatement (oracle/image_step_spec.py,
+built on pieces pinned to the reference's outputs).  fp32; values 1e-4; gradients strict in the smooth (slopes = 1)
+network and kink-tolerant with real slopes (oracle.gridnet_spec.test_params explains why)."""
+import pytest
+import torch
+
+from oracle import gridnet_spec as G
+from oracle import image_step_spec as S
+from test_hip_gridnet import check_grads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("flip", [False, True])
+@pytest.mark.parametrize("arch,linear", [("GridNet", True), ("GridNet", False), ("CoordGridNet", True)])
+def test_reference_step_body(dev, arch, linear, flip):
+    from vlg.image_engine import ImageEngine, synthetic_frames
+    b, H, W, filt = 2, 32, 40, (8, 16, 24)
+    coord = arch == "CoordGridNet"
+    eng = ImageEngine(b, H, W, dev, arch=arch, filters=filt)
+    p = G.test_params(G.param_shapes(10, filt, coord=coord), seed=5, linear=linear)
+    eng.load_state_dict(p)
+    batch = synthetic_frames(b, H, W, seed=21)
+    parts, grads = S.loss_and_grads(p, batch, coord, flip)
+    eng.forward({k: v.to(dev) for k, v in batch.items()}, flip=flip)
+    eng.backward()
+    got = eng.losses.cpu()
+    for i, name in enumerate(("l1", "gradient", "ssim", "ce")):
+        assert abs(float(got[i]) - parts[i]) <= 1e-4 * abs(parts[i]), (name, float(got[i]), parts[i])
+    assert abs(float(eng.total()) - parts[4]) <= 1e-4 * abs(parts[4])
+    check_grads(eng.net.named_grads(), grads, linear, tol=3e-4)
+
+
+def test_adam_steps_reduce_the_loss(dev):
+    from vlg.image_engine import ImageEngine, synthetic_frames
+    eng = ImageEngine(2, 32, 32, dev, arch="CoordGridNet", filters=(8, 16, 24), lr=2e-3)
+    eng.load_state_dict(G.test_params(G.param_shapes(10, (8, 16, 24), coord=True), seed=1))
+    batch = {k: v.to(dev) for k, v in synthetic_frames(2, 32, 32, seed=3).items()}
+    first = float(eng.train_step(batch))
+    for _ in range(30):
+        last = float(eng.train_step(batch))
+    assert last < 0.95 * first, (first, last)
+    sd = eng.state_dict()                        # still exports in the reference's key/shape format
+    assert tuple(sd["lateral_in.conv.0.conv.weight"].shape) == (8, 12, 3, 3)

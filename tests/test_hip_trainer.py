@@ -45,3 +45,29 @@ def test_trainer_on_gpu_matches_oracle_trainer(tmp_path, monkeypatch):
     assert torch.equal(again.engine.exp_avg_sq, hip_tr.engine.exp_avg_sq)
     c, b = again.generate_sequence(*[next(iter(again.val_loader))[k] for k in ("slot_class", "slot_box")], steps=8)
     assert c.shape == (4, 8, 8) and b.shape == (4, 8, 8, 4) and bool(torch.isfinite(b).all())
+
+
+def test_trainer_runs_the_reference_model(tmp_path, monkeypatch):
+    """VLG_MODEL=gridnet: main.py's default --arch CoordGridNet trains the reference's own model and losses
+    (reference src/trainer.py:193-258) on synthetic frame triplets through the same Trainer surface."""
+    (tmp_path / "src").mkdir()
+    monkeypatch.chdir(tmp_path / "src")
+    monkeypatch.setenv("VLG_MODEL", "gridnet")
+    monkeypatch.setenv("VLG_IMG_SIZE", "32")
+    from trainer import Trainer
+    random.seed(1024)
+    args = reference_args(tmp_path / "exp", batch_size=2, epochs=2, print_freq=1, train_clips=8, val_clips=4, lr=2e-3)
+    tr = Trainer(args)
+    assert tr.image_mode and tr.device.type == "cuda"
+    vals = []
+    for epoch in range(args.epochs):
+        tr.set_epoch(epoch)
+        tr.train()
+        vals.append(tr.validate()["loss"])
+    assert vals[1] < vals[0]
+    tr.save_checkpoint({"loss": vals[-1]})
+    ck = torch.load("../checkpoint/latest.pth", weights_only=True)
+    assert ck["arch"] == "CoordGridNet" and tuple(ck["gridnet"]["lateral_in.conv.0.conv.weight"].shape) == (32, 12, 3, 3)
+    again = Trainer(reference_args(tmp_path / "again", resume="../checkpoint/latest.pth", batch_size=2, epochs=1,
+                                   print_freq=1, train_clips=8, val_clips=4))
+    assert torch.equal(again.engine.engine.net.params, tr.engine.engine.net.params)

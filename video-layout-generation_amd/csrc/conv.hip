@@ -245,6 +245,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
                     if (g.epi & VLG_CEPI_RESID) v += g.aux_in[o];
                     if (g.epi & VLG_CEPI_PRELU) v = prelu_f(v, slope);
                     if (g.rowmask != nullptr) v *= g.rowmask[row];
+                    // data gradient: appended AddCoords channels are constants, not outputs of the producing conv -
+                    // their gradient must not flow on (it would train weight rows that no forward pass uses)
+                    if (MODE == CONV_DGRAD && col >= g.act_ch) v = 0.f;
                     if (g.epi & VLG_CEPI_DPRELU) {
                         const float x = g.aux_in[o];
                         if (col < g.act_ch) {

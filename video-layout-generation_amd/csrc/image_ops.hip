@@ -259,6 +259,29 @@ __global__ __launch_bounds__(IMG_BLOCK) void prep_input_kernel(
     }
 }
 
+// per-channel affine on (b,C,H,W): dst = (src - shift[c]) * scale[c]   (C <= 4)
+// forward:  img = (img - mean_arr) / std_arr          reference src/trainer.py:212  (scale = 1/std, shift = mean)
+// backward: d img_raw = d img / std_arr               (shift = 0)
+__global__ __launch_bounds__(IMG_BLOCK) void affine_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                               int64_t n, int C, int64_t hw, float4 shift, float4 scale) {
+    const float sh[4] = {shift.x, shift.y, shift.z, shift.w}, sc[4] = {scale.x, scale.y, scale.z, scale.w};
+    for (int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IMG_BLOCK) {
+        const int c = (int)((i / hw) % C);
+        dst[i] = (src[i] - sh[c]) * sc[c];
+    }
+}
+
+extern "C" int vlg_affine_nchw(const float* src, float* dst, int b, int C, int64_t hw, const float* shift_host,
+                               const float* scale_host, void* stream) {
+    if (b < 1 || C < 1 || C > 4 || hw < 1) return VLG_ERR_SHAPE;
+    float sh[4] = {0, 0, 0, 0}, sc[4] = {1, 1, 1, 1};
+    for (int c = 0; c < C; ++c) { sh[c] = shift_host[c]; sc[c] = scale_host[c]; }
+    const int64_t n = (int64_t)b * C * hw;
+    hipLaunchKernelGGL(affine_nchw_kernel, dim3(img_blocks(n)), dim3(IMG_BLOCK), 0, (hipStream_t)stream, src, dst, n, C, hw,
+                       make_float4(sh[0], sh[1], sh[2], sh[3]), make_float4(sc[0], sc[1], sc[2], sc[3]));
+    return vlg_last_error();
+}
+
 extern "C" int vlg_image_loss_scratch(void) { return IMG_SCRATCH; }
 
 extern "C" int vlg_ce_nchw(const float* logits, const int64_t* target, float* dlogits, float* loss, float* scratch,

@@ -14,6 +14,11 @@ Shape knobs the reference CLI does not have are read with getattr/env defaults s
 byte-for-byte unchanged:  VLG_FRAMES (T, 16), VLG_SLOTS (N, 64), VLG_DMODEL (d, 256),
 VLG_LAYERS (4), VLG_TRAIN_CLIPS (1024), VLG_VAL_CLIPS (256), VLG_VARIABLE_N (0).
 
+VLG_MODEL=gridnet switches the step to the reference's OWN model and losses (vlg/image_engine.py:
+--arch GridNet|CoordGridNet on the conv3x3 MFMA kernels, 40 L1 + 20 (GradientLoss + SSIM) + 10 CE, reference
+src/trainer.py:193-258) on synthetic frame triplets of VLG_IMG_SIZE (256) pixels; the default (layout) is the
+token step BASELINE.json's metric is quoted on.
+
 Repairs of reference defects, all stated: gradients are overwritten each
 step (A-5 zero_grad), the train log line uses the `loss` key (A-6), one checkpoint schema
 {'epoch','arch','gridnet','optimizer'} for save/--ckpt/--resume (A-1,A-8,A-9), `.model` exists
@@ -118,6 +123,61 @@ def get_layout_engine(args, cfg: Optional[LayoutConfig] = None, engine_factory: 
 get_gridnet = get_layout_engine     # reference name (src/trainer.py:81)
 
 
+class _ImageModel:
+    """Adapter giving vlg.image_engine.ImageEngine the few methods Trainer uses on the layout engine."""
+
+    def __init__(self, args, batch: int):
+        from vlg.image_engine import IMAGE_KEYS, ImageEngine
+        size = _knob(args, "img_size", "VLG_IMG_SIZE", 256)
+        self.keys = IMAGE_KEYS
+        self.size = size
+        self.device = torch.device("cuda", int(args.rank))
+        arch = args.arch if args.arch in ("GridNet", "CoordGridNet") else "CoordGridNet"
+        self.engine = ImageEngine(batch, size, size, self.device, arch=arch, lr=float(getattr(args, "lr", ADAM_LR)),
+                                  beta1=float(getattr(args, "beta1", ADAM_BETA1)))
+        torch.manual_seed(int(getattr(args, "seed", SEED)))          # same init on every rank (main.py:57-60)
+        sd = {}
+        for k, shp in self.engine.net.reference_shapes().items():    # torch defaults: kaiming-uniform convs, slope 0.25
+            if len(shp) == 4:
+                bound = 1.0 / (shp[1] * 9) ** 0.5
+                sd[k] = (torch.rand(shp) * 2 - 1) * bound
+            elif shp == (1,):
+                sd[k] = torch.full(shp, 0.25)
+            else:
+                sd[k] = (torch.rand(shp) * 2 - 1) * (1.0 / (self.engine.net.reference_shapes()[k[:-4] + "weight"][1] * 9) ** 0.5)
+        self.engine.load_state_dict(sd)
+        self.world = max(int(getattr(args, "gpus", 1) or 1), 1)
+        self.step_count = 0
+
+    def named_params(self):
+        return self.engine.state_dict()
+
+    def load_params(self, sd):
+        self.engine.load_state_dict(sd)
+
+    def optimizer_state(self):
+        e = self.engine
+        return {"exp_avg": e.exp_avg.cpu().clone(), "exp_avg_sq": e.exp_avg_sq.cpu().clone(), "step": int(e.step_count),
+                "lr": e.lr, "beta1": e.beta1}
+
+    def load_optimizer(self, st):
+        e = self.engine
+        e.exp_avg.copy_(st["exp_avg"]); e.exp_avg_sq.copy_(st["exp_avg_sq"]); e.step_count = int(st["step"])
+
+    def train_step(self, batch, flip: bool):
+        e = self.engine
+        e.forward(batch, flip)
+        e.backward()
+        if self.world > 1 and dist.is_initialized():                # DDP's gradient mean (reference trainer.py:113)
+            dist.all_reduce(e.net.grads)
+        e.adam_step(1.0 / self.world)
+        return e.total().reshape(1)
+
+    def eval_loss(self, batch):
+        self.engine.forward(batch, flip=False, want_grads=False)
+        return self.engine.total().reshape(1)
+
+
 class _ModelHandle:
     """`trainer.model` / `trainer.gridnet`: main.py:65 calls trainer.model.eval()."""
 
@@ -150,13 +210,17 @@ class Trainer:
         if torch.cuda.is_available() and engine_factory is None:
             torch.cuda.set_device(int(args.rank))               # reference src/trainer.py:110
         self.cfg = layout_config(args)
-        self.engine = get_layout_engine(args, self.cfg, engine_factory)
+        self.image_mode = engine_factory is None and os.environ.get("VLG_MODEL", "layout").lower() == "gridnet"
+        self.reducer = None
+        if self.image_mode:
+            self.engine = _ImageModel(args, self.cfg.B)
+        else:
+            self.engine = get_layout_engine(args, self.cfg, engine_factory)
+            if self.distributed:                                # replaces the DDP wrappers, trainer.py:113,115
+                self.reducer = GradReducer(self.engine.grads_ext,
+                                           bucket_ranges(self.engine.layout, self.engine.n_params, self.cfg.n_layers))
         self.device = self.engine.device
         self.gridnet = self.model = _ModelHandle(self.engine)   # reference attr `gridnet`; main.py:65 wants `.model`
-        self.reducer = None
-        if self.distributed:                                    # replaces the DDP wrappers, trainer.py:113,115
-            self.reducer = GradReducer(self.engine.grads_ext,
-                                       bucket_ranges(self.engine.layout, self.engine.n_params, self.cfg.n_layers))
         self.global_step = 0
         self.epoch = 0
         if getattr(args, "resume", None) is not None:           # reference src/trainer.py:138-139
@@ -167,11 +231,17 @@ class Trainer:
         variable_n = bool(_knob(args, "variable_n", "VLG_VARIABLE_N", 0))
         n_train = _knob(args, "train_clips", "VLG_TRAIN_CLIPS", 1024)
         n_val = _knob(args, "val_clips", "VLG_VAL_CLIPS", 256)
-        mk = dict(T=self.cfg.T, N=self.cfg.N, n_classes=self.cfg.n_classes, variable_n=variable_n)
-        train_clips = synthetic_clips(n_train, seed=seed, **mk)          # get_dataset(), trainer.py:144
-        val_clips = synthetic_clips(n_val, seed=seed + 1, **mk)
-        Loader = BucketedClipLoader if variable_n else ClipLoader
         common = dict(batch=self.cfg.B, rank=int(args.rank), world=self.world, seed=seed)
+        if self.image_mode:
+            from vlg.image_engine import synthetic_frames
+            sz = self.engine.size
+            train_clips, val_clips = synthetic_frames(n_train, sz, sz, seed=seed), synthetic_frames(n_val, sz, sz, seed=seed + 1)
+            Loader, common["keys"] = ClipLoader, self.engine.keys
+        else:
+            mk = dict(T=self.cfg.T, N=self.cfg.N, n_classes=self.cfg.n_classes, variable_n=variable_n)
+            train_clips = synthetic_clips(n_train, seed=seed, **mk)      # get_dataset(), trainer.py:144
+            val_clips = synthetic_clips(n_val, seed=seed + 1, **mk)
+            Loader = BucketedClipLoader if variable_n else ClipLoader
         self.train_loader = Loader(train_clips, shuffle=True, **common)   # DistributedSampler + DataLoader, :145-152
         self.val_loader = Loader(val_clips, shuffle=False, **common)
         args.logger.debug("Finish init trainer")
@@ -202,12 +272,20 @@ class Trainer:
         end = time()
         n_batches = len(self.train_loader)
         for i, batch in enumerate(self.train_loader):
-            batch = to_device(self._flip(batch), self.device)     # H2D, reference src/trainer.py:184-187
+            if self.image_mode:                                   # flip is done by vlg_prep_input (trainer.py:200-206)
+                flip = random.random() < 0.5
+                batch = to_device(batch, self.device, self.engine.keys)
+            else:
+                batch = to_device(self._flip(batch), self.device)     # H2D, reference src/trainer.py:184-187
             load_time = time() - end
             end = time()
             self.global_step += 1
             # forward, 40/20/10 loss, backward, bucketed all-reduce, Adam: reference src/trainer.py:209-258
-            loss = self.engine.train_step(batch, self.reducer)
+            if self.image_mode:
+                loss = self.engine.train_step(batch, flip)
+                self.sync([loss])                                 # logged value = cross-rank mean (trainer.py:256)
+            else:
+                loss = self.engine.train_step(batch, self.reducer)
             if int(self.args.rank) == 0 and i % int(self.args.print_freq) == 0:
                 # with a reducer the 4 loss floats were summed over ranks inside the first gradient
                 # bucket: logged value = cross-rank mean, as sync() gave the reference (trainer.py:256)
@@ -230,11 +308,15 @@ class Trainer:
         end = time()
         n_batches = len(self.val_loader)
         for i, batch in enumerate(self.val_loader):
-            batch = to_device(batch, self.device)
+            keys = self.engine.keys if self.image_mode else BATCH_KEYS
+            batch = to_device(batch, self.device, keys)
             load_time = time() - end
             end = time()
-            loss = self.engine.forward(batch)[0:1].clone()          # forward only, reference src/trainer.py:320-333
-            size = torch.tensor([float(batch["slot_class"].shape[0])], device=loss.device)
+            if self.image_mode:
+                loss = self.engine.eval_loss(batch).clone()
+            else:
+                loss = self.engine.forward(batch)[0:1].clone()      # forward only, reference src/trainer.py:320-333
+            size = torch.tensor([float(batch[keys[0]].shape[0])], device=loss.device)
             loss.mul_(size)
             self.sync([loss, size], mean=False)                     # size-weighted SUM, trainer.py:336-338
             loss.div_(size)                                         # / GLOBAL clip count (see module docstring)

@@ -41,8 +41,8 @@ def synthetic_clips(n_clips: int, T: int, N: int, n_classes: int = 20, seed: int
             "tgt_box": box[:, 1:].contiguous(), "valid": valid, "n_valid": n_valid}
 
 
-def to_device(batch: Dict[str, torch.Tensor], device: torch.device) -> Dict[str, torch.Tensor]:
-    return {k: batch[k].to(device, non_blocking=True).contiguous() for k in BATCH_KEYS}
+def to_device(batch: Dict[str, torch.Tensor], device: torch.device, keys=BATCH_KEYS) -> Dict[str, torch.Tensor]:
+    return {k: batch[k].to(device, non_blocking=True).contiguous() for k in keys}
 
 
 def shard_indices(n_items: int, rank: int, world: int, epoch: int, seed: int, shuffle: bool = True) -> List[int]:
@@ -62,10 +62,11 @@ class ClipLoader:
     """Fixed-shape loader: every batch is (B, T, N) clips from one synthetic pool."""
 
     def __init__(self, clips: Dict[str, torch.Tensor], batch: int, rank: int = 0, world: int = 1,
-                 seed: int = 1024, shuffle: bool = True, device: Optional[torch.device] = None):
+                 seed: int = 1024, shuffle: bool = True, device: Optional[torch.device] = None, keys=BATCH_KEYS):
         self.clips, self.batch, self.rank, self.world = clips, batch, rank, world
         self.seed, self.shuffle, self.device, self.epoch = seed, shuffle, device, 0
-        self.n = clips["slot_class"].shape[0]
+        self.keys = tuple(keys)
+        self.n = clips[self.keys[0]].shape[0]
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
@@ -80,8 +81,8 @@ class ClipLoader:
         idx = self._indices()
         for i in range(len(self)):
             sel = torch.tensor(idx[i * self.batch:(i + 1) * self.batch])
-            b = {k: self.clips[k][sel] for k in BATCH_KEYS}
-            yield to_device(b, self.device) if self.device is not None else b
+            b = {k: self.clips[k][sel] for k in self.keys}
+            yield to_device(b, self.device, self.keys) if self.device is not None else b
 
 
 class BucketedClipLoader(ClipLoader):

@@ -42,6 +42,7 @@ SIGNATURES = {
     "vlg_l1_mean": (I, [P, P, P, P, P, L, F, P]),
     "vlg_gradient_loss": (I, [P, P, P, P, P, I, I, I, F, P]),
     "vlg_ssim_loss": (I, [P, P, P, P, P, I, I, I, I, F, P]),
+    "vlg_affine_nchw": (I, [P, P, I, I, L, P, P, P]),
     "vlg_prep_input": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vlg_conv3x3_fwd": (I, [P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, P]),
     "vlg_conv3x3_dgrad_slabs": (I, [L, I]),
