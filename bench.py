@@ -38,7 +38,7 @@ KERNEL_OF_FAMILY = {             # rocprofv3 kernel names (profiles/) for each t
 }
 
 
-def cpu_baseline(cfg, budget_s: float = 20.0):
+def cpu_baseline(cfg, budget_s: float = 12.0):
     """Times the CPU oracle (the only CPU implementation of this step: the reference has none)
     on a bounded sample: same T, N, d, depth; fewer clips per step so it fits the budget."""
     from oracle import layout_spec as O
@@ -46,7 +46,7 @@ def cpu_baseline(cfg, budget_s: float = 20.0):
     # the GPU box gives a one-GPU job a 16-core share; more threads than that only oversubscribes
     threads = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
-    B = min(cfg.B, 2)
+    B = min(cfg.B, 8)
     p = O.init_params(param_shapes(cfg), seed=1024)
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(x) for k, x in p.items()}
@@ -64,7 +64,7 @@ def cpu_baseline(cfg, budget_s: float = 20.0):
         step(n + 2)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 8:
+        if el > budget_s or n >= 400:
             break
     return {"value": round(B * n / el, 3), "unit": "clips/s", "cores": threads, "kind": "port",
             "sample": "%d steps of %d clips (T=%d,N=%d,d=%d,L=%d), torch-CPU oracle fwd+bwd+Adam, %.1f s"
