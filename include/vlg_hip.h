@@ -75,6 +75,8 @@ int vlg_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
 #define VLG_EPI_GELU   2   /* aux_out = pre-activation, C = gelu(pre)   (needs BIAS) */
 #define VLG_EPI_RESID  4   /* C = acc (+bias) + aux_in[row,col]                      */
 #define VLG_EPI_DGELU  8   /* C = acc * gelu'(aux_in[row,col])                       */
+#define VLG_EPI_BF16   16  /* operands rounded to bf16 for v_mfma_f32_32x32x16_bf16, fp32 accumulate and fp32
+                              tensors in HBM (BASELINE.json configs[2]); default is exact-fp32 MFMA  */
 int vlg_linear_fwd(const float* A, int lda, const float* W, int ldw, const float* bias,
                    float* C, int ldc, const float* aux_in, float* aux_out,
                    int64_t M, int N, int K, int epilogue, void* stream);
@@ -84,7 +86,7 @@ int vlg_linear_dgrad(const float* dY, int ldy, const float* W, int ldw,
 int vlg_linear_wgrad_slabs(int64_t M, int N, int K);
 int vlg_linear_wgrad(const float* dY, int ldy, const float* X, int ldx,
                      float* slabs, int64_t slab_stride,
-                     int64_t M, int N, int K, void* stream);
+                     int64_t M, int N, int K, int flags /* 0 or VLG_EPI_BF16 */, void* stream);
 
 /* ------------------------------------------------------------------- attention
  * Temporal encoder core: causal softmax attention along T for each (clip, slot,

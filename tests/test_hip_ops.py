@@ -156,7 +156,7 @@ def test_linear_dgrad_wgrad(H, dev, M, N, K):
     ns = H.load().vlg_linear_wgrad_slabs(M, N, K)
     stride = N * K + N
     slabs = torch.full((ns * stride,), float("nan"), device=dev)
-    H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, M, N, K, stream())
+    H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, M, N, K, 0, stream())
     g = reduce_slabs(H, slabs, stride, ns, stride, dev)
     sc = math.sqrt(M)
     assert_close(g[:N * K].view(N, K) / sc, (dy.double().t() @ x.double()).float() / sc, rtol=1e-4, atol=1e-5, what="wgrad")

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--T", type=int, default=16)
     ap.add_argument("--N", type=int, default=64)
     ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--bf16", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = hip.load()
@@ -41,6 +42,7 @@ def main():
     red_dst = torch.empty(ff * d + ff, device=dev)            # reduce target: [w | b] of the largest projection
     stats = r(2, M)
     g = r(d)
+    FLAGS = 16 if a.bf16 else 0
     cases = []
 
     def add(name, work, unit, fn):
@@ -49,17 +51,17 @@ def main():
 
     P = lambda t: t.data_ptr()
     fl = lambda n, k: 2.0 * M * n * k
-    add("gemm fwd qkv  (bias)", fl(3 * d, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_qkv), d, P(bias), P(y_3d), 3 * d, 0, 0, M, 3 * d, d, EPI_BIAS, S))
-    add("gemm fwd proj (bias+resid)", fl(d, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_proj), d, P(bias), P(y_d), d, P(x_d), 0, M, d, d, EPI_BIAS | EPI_RESID, S))
-    add("gemm fwd ff1  (bias+gelu)", fl(ff, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_ff1), d, P(bias), P(y_ff), ff, 0, P(x_ff2), M, ff, d, EPI_BIAS | EPI_GELU, S))
-    add("gemm fwd ff2  (bias+resid)", fl(d, ff), "F", lambda: hip.call("vlg_linear_fwd", P(x_ff), ff, P(w_ff2), ff, P(bias), P(y_d), d, P(x_d), 0, M, d, ff, EPI_BIAS | EPI_RESID, S))
-    add("gemm dgrad qkv", fl(3 * d, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_3d), 3 * d, P(w_qkv), d, P(y_d), d, 0, M, 3 * d, d, EPI_NONE, S))
-    add("gemm dgrad proj", fl(d, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_proj), d, P(y_d), d, 0, M, d, d, EPI_NONE, S))
-    add("gemm dgrad ff1", fl(ff, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_ff), ff, P(w_ff1), d, P(y_d), d, 0, M, ff, d, EPI_NONE, S))
-    add("gemm dgrad ff2 (dgelu)", fl(d, ff), "F", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(y_ff), ff, P(x_ff2), M, d, ff, EPI_DGELU, S))
+    add("gemm fwd qkv  (bias)", fl(3 * d, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_qkv), d, P(bias), P(y_3d), 3 * d, 0, 0, M, 3 * d, d, EPI_BIAS | FLAGS, S))
+    add("gemm fwd proj (bias+resid)", fl(d, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_proj), d, P(bias), P(y_d), d, P(x_d), 0, M, d, d, EPI_BIAS | EPI_RESID | FLAGS, S))
+    add("gemm fwd ff1  (bias+gelu)", fl(ff, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_ff1), d, P(bias), P(y_ff), ff, 0, P(x_ff2), M, ff, d, EPI_BIAS | EPI_GELU | FLAGS, S))
+    add("gemm fwd ff2  (bias+resid)", fl(d, ff), "F", lambda: hip.call("vlg_linear_fwd", P(x_ff), ff, P(w_ff2), ff, P(bias), P(y_d), d, P(x_d), 0, M, d, ff, EPI_BIAS | EPI_RESID | FLAGS, S))
+    add("gemm dgrad qkv", fl(3 * d, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_3d), 3 * d, P(w_qkv), d, P(y_d), d, 0, M, 3 * d, d, EPI_NONE | FLAGS, S))
+    add("gemm dgrad proj", fl(d, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_proj), d, P(y_d), d, 0, M, d, d, EPI_NONE | FLAGS, S))
+    add("gemm dgrad ff1", fl(ff, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_ff), ff, P(w_ff1), d, P(y_d), d, 0, M, ff, d, EPI_NONE | FLAGS, S))
+    add("gemm dgrad ff2 (dgelu)", fl(d, ff), "F", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(y_ff), ff, P(x_ff2), M, d, ff, EPI_DGELU | FLAGS, S))
     for nm, n, k, dy, xx in (("qkv", 3 * d, d, x_3d, x_d), ("proj", d, d, y_d, x_d), ("ff1", ff, d, x_ff, x_d), ("ff2", d, ff, x_d, x_ff)):
         ns = lib.vlg_linear_wgrad_slabs(M, n, k)
-        add("gemm wgrad %-4s (%d slabs)" % (nm, ns), fl(n, k), "F", lambda n=n, k=k, dy=dy, xx=xx: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, M, n, k, S))
+        add("gemm wgrad %-4s (%d slabs)" % (nm, ns), fl(n, k), "F", lambda n=n, k=k, dy=dy, xx=xx: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, M, n, k, FLAGS, S))
         add("reduce wgrad %-4s" % nm, 4.0 * (n * k + n) * (ns + 1), "B", lambda n=n, k=k, ns=ns: hip.call("vlg_reduce_slabs", P(slabs), n * k + n, ns, P(red_dst), n * k + n, S))
     add("attention fwd", 16.0 * M * d, "B", lambda: hip.call("vlg_attention_fwd", P(x_3d), P(y_d), B * N, T, d, S))
     add("attention bwd", 28.0 * M * d, "B", lambda: hip.call("vlg_attention_bwd", P(x_3d), P(x_d), P(y_3d), B * N, T, d, S))

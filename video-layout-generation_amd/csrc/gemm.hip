@@ -39,7 +39,7 @@ struct GemmArgs {
     unsigned long long* clock_probe;   // diagnostic only (VLG_GEMM_CLOCK_PROBE): {shader ticks, 100 MHz ticks} per block
 };
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool BF16>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int WM = (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 4 : 1);
     constexpr int WN = 4 / WM;
@@ -94,6 +94,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     float4 ra[TA::NV], rb[TB::NV];
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
     auto chunk = [&](const float* as, const float* bs, int s) {
+        if constexpr (BF16) {
+            // mixed precision: operands rounded to bf16 at fragment-read time, fp32 accumulate.  One call covers
+            // 8 k-values like the fp32 path, so two calls make one 16-deep MFMA: do the work on even s only.
+            if (s & 1) return;
+            bf16x8 a16[TM], b16[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a16[i] = TA::frag16(as, (wm * TM + i) * 32 + l31, s >> 1, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b16[j] = TB::frag16(bs, (wn * TN + j) * 32 + l31, s >> 1, h);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a16[i], b16[j], acc[i][j], 0, 0, 0);
+            return;
+        }
         float a[TM][4], b[TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i) TA::frag(a[i], as, (wm * TM + i) * 32 + l31, s, h);
@@ -217,22 +233,26 @@ static int gemm_bk_override() {
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
-static int launch_gemm(GemmArgs g, hipStream_t s) {
+static int launch_gemm(GemmArgs g, hipStream_t s, bool bf16 = false) {
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (g.N + BN - 1) / BN;
     const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.splits;
     if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
     const dim3 grid((unsigned)blocks), block(GEMM_THREADS);
     g.clock_probe = vlg_gemm_clock_probe;
+    if (bf16) {   // bf16 MFMA: the loop is staging-bound, so the deeper tile (fewer barriers per byte) is used
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM, true>), grid, block, 0, s, g);
+        return vlg_last_error();
+    }
     if constexpr (BM == 128 && BN == 128) {
         const int forced = gemm_bk_override();
         const bool heavy_epilogue = (EPI & (VLG_EPI_GELU | VLG_EPI_DGELU)) != 0;
         if (forced == 16 || (forced != 32 && heavy_epilogue)) {
-            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, A_KC, B_KC, EPI, COLSUM>), grid, block, 0, s, g);
+            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, A_KC, B_KC, EPI, COLSUM, false>), grid, block, 0, s, g);
             return vlg_last_error();
         }
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM>), grid, block, 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM, false>), grid, block, 0, s, g);
     return vlg_last_error();
 }
 
@@ -248,18 +268,20 @@ extern "C" int vlg_linear_fwd(const float* A, int lda, const float* W, int ldw, 
     g.M = M; g.N = N; g.Kc = K; g.lda = lda; g.ldb = ldw; g.ldc = ldc;
     g.splits = 1; g.kc_per_split = K; g.slab_stride = 0; g.colsum_off = 0;
     hipStream_t s = (hipStream_t)stream;
+    const bool bf16 = (epilogue & VLG_EPI_BF16) != 0;
+    epilogue &= ~VLG_EPI_BF16;
     if ((epilogue & VLG_EPI_BIAS) && !bias) return VLG_ERR_SHAPE;
     if ((epilogue & (VLG_EPI_RESID | VLG_EPI_DGELU)) && !aux_in) return VLG_ERR_SHAPE;
     if ((epilogue & VLG_EPI_GELU) && !aux_out) return VLG_ERR_SHAPE;
     const bool narrow = N <= 32;
     switch (epilogue) {
         case VLG_EPI_BIAS:
-            return narrow ? launch_gemm<128, 32, true, true, VLG_EPI_BIAS, false>(g, s)
-                          : launch_gemm<128, 128, true, true, VLG_EPI_BIAS, false>(g, s);
+            return narrow ? launch_gemm<128, 32, true, true, VLG_EPI_BIAS, false>(g, s, bf16)
+                          : launch_gemm<128, 128, true, true, VLG_EPI_BIAS, false>(g, s, bf16);
         case VLG_EPI_BIAS | VLG_EPI_GELU:
-            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false>(g, s);
+            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false>(g, s, bf16);
         case VLG_EPI_BIAS | VLG_EPI_RESID:
-            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false>(g, s);
+            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false>(g, s, bf16);
         default:
             return VLG_ERR_SHAPE;
     }
@@ -275,12 +297,14 @@ extern "C" int vlg_linear_dgrad(const float* dY, int ldy, const float* W, int ld
     g.M = M; g.N = K; g.Kc = N; g.lda = ldy; g.ldb = ldw; g.ldc = ldx;
     g.splits = 1; g.kc_per_split = N;
     hipStream_t s = (hipStream_t)stream;
+    const bool bf16 = (epilogue & VLG_EPI_BF16) != 0;
+    epilogue &= ~VLG_EPI_BF16;
     switch (epilogue) {
         case VLG_EPI_NONE:
-            return launch_gemm<128, 128, true, false, VLG_EPI_NONE, false>(g, s);
+            return launch_gemm<128, 128, true, false, VLG_EPI_NONE, false>(g, s, bf16);
         case VLG_EPI_DGELU:
             if (!aux_in) return VLG_ERR_SHAPE;
-            return launch_gemm<128, 128, true, false, VLG_EPI_DGELU, false>(g, s);
+            return launch_gemm<128, 128, true, false, VLG_EPI_DGELU, false>(g, s, bf16);
         default:
             return VLG_ERR_SHAPE;
     }
@@ -308,7 +332,7 @@ extern "C" int vlg_linear_wgrad_slabs(int64_t M, int N, int K) {
 }
 
 extern "C" int vlg_linear_wgrad(const float* dY, int ldy, const float* X, int ldx, float* slabs,
-                                int64_t slab_stride, int64_t M, int N, int K, void* stream) {
+                                int64_t slab_stride, int64_t M, int N, int K, int flags, void* stream) {
     // slab[s][n*K + k] = sum_{m in split s} dY[m,n] X[m,k] ;  slab[s][N*K + n] = sum_m dY[m,n]
     if (M < 1 || N < 4 || (N & 3) || K < 4 || (K & 3) || ldy < N || ldx < K) return VLG_ERR_SHAPE;
     if (slab_stride < (int64_t)N * K + N) return VLG_ERR_SHAPE;
@@ -319,6 +343,7 @@ extern "C" int vlg_linear_wgrad(const float* dY, int ldy, const float* X, int ld
     wgrad_plan(M, N, K, &g.splits, &g.kc_per_split);
     g.slab_stride = slab_stride; g.colsum_off = (int64_t)N * K;
     hipStream_t s = (hipStream_t)stream;
-    return N <= 32 ? launch_gemm<32, 128, false, false, VLG_EPI_NONE, true>(g, s)
-                   : launch_gemm<128, 128, false, false, VLG_EPI_NONE, true>(g, s);
+    const bool bf16 = (flags & VLG_EPI_BF16) != 0;
+    return N <= 32 ? launch_gemm<32, 128, false, false, VLG_EPI_NONE, true>(g, s, bf16)
+                   : launch_gemm<128, 128, false, false, VLG_EPI_NONE, true>(g, s, bf16);
 }

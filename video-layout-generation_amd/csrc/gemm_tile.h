@@ -4,6 +4,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define GEMM_THREADS 256
 
@@ -48,6 +49,22 @@ struct Tile {
             if constexpr (KC) st4(S + (idx / PER_ROW) * LDK + ((idx % PER_ROW) << 2), r[i]);
             else st4(S + (idx << 2), r[i]);
         }
+    }
+    // bf16 MFMA (32x32x16) fragment: the 8 k-values k = 16s + 8h + j of tile row `row`, rounded to bf16 (RNE)
+    // on the way from the fp32 LDS tile to the MFMA - HBM, staging and LDS layouts stay the fp32 ones
+    __device__ static __forceinline__ bf16x8 frag16(const float* S, int row, int s, int h) {
+        float f[8];
+        if constexpr (KC) {
+            const float4 t0 = ld4(S + row * LDK + 16 * s + 8 * h), t1 = ld4(S + row * LDK + 16 * s + 8 * h + 4);
+            f[0] = t0.x; f[1] = t0.y; f[2] = t0.z; f[3] = t0.w; f[4] = t1.x; f[5] = t1.y; f[6] = t1.z; f[7] = t1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = S[(16 * s + 8 * h + j) * BR + row];
+        }
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (__bf16)f[j];
+        return r;
     }
     // 4 fragment values of tile row `row` for chunk s, lane half h:  k = 8s + 4h + j
     __device__ static __forceinline__ void frag(float (&f)[4], const float* S, int row, int s, int h) {

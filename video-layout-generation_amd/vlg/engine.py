@@ -58,8 +58,15 @@ class LayoutEngine:
     """Owns parameters, optimiser state and workspace; runs forward/backward/Adam."""
 
     def __init__(self, cfg: LayoutConfig, device: torch.device, seed: int = 1024,
-                 lr: float = ADAM_LR, beta1: float = ADAM_BETA1):
+                 lr: float = ADAM_LR, beta1: float = ADAM_BETA1, precision: str = "fp32"):
+        """precision: "fp32" = exact-fp32 MFMA projections (parity 1e-4); "bf16" = projection operands rounded
+        to bf16 for the 16x faster bf16 MFMA, fp32 accumulate, every tensor still fp32 in HBM (BASELINE.json
+        configs[2]); everything else (norms, attention, losses, Adam, master weights) is fp32 in both."""
         cfg.validate()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be fp32 or bf16")
+        self.precision = precision
+        self.gemm_flags = hip.EPI_BF16 if precision == "bf16" else 0
         hip.load()                                   # fail loudly before touching the GPU
         if device.type != "cuda":
             raise hip.HipError("LayoutEngine needs a HIP device (got %s); there is no CPU path" % device)
@@ -162,22 +169,24 @@ class LayoutEngine:
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
-    def _timed(self, family: str, flops: float, name: str, *args) -> None:
+    def _timed(self, family: str, flops: float, name: str, *args, nbytes: float = 0.0) -> None:
         """Launch through the C ABI; when a timer is attached, bracket the launch with events on
         the launch stream (torch's current stream IS the stream handed to the kernel)."""
         if self.timer is None or (self.timer.only is not None and family not in self.timer.only):
             call(name, *args)
         else:
-            with self.timer.section(family, flops):
+            with self.timer.section(family, flops, nbytes):
                 call(name, *args)
 
     def _linear(self, a, w, b, c, M, N, K, epi, aux_in=None, aux_out=None):
+        nb = 4.0 * (M * K + N * K + M * N * (1 + (aux_in is not None) + (aux_out is not None)))
         self._timed("gemm_fwd" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_fwd", ptr(a), K, ptr(w), K,
-                    ptr(b), ptr(c), N, ptr(aux_in), ptr(aux_out), M, N, K, epi, self._stream())
+                    ptr(b), ptr(c), N, ptr(aux_in), ptr(aux_out), M, N, K, epi | self.gemm_flags, self._stream(), nbytes=nb)
 
     def _dgrad(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux_in=None):
+        nb = 4.0 * (M * N + N * K + M * K * (1 + (aux_in is not None)))
         self._timed("gemm_dgrad", 2.0 * M * N * K, "vlg_linear_dgrad", ptr(dy), N, ptr(w), K, ptr(dx), K,
-                    ptr(aux_in), M, N, K, epi, self._stream())
+                    ptr(aux_in), M, N, K, epi | self.gemm_flags, self._stream(), nbytes=nb)
 
     def _wgrad(self, dy, x, wname, M, N, K):
         """grad[w | b] = (dy^T . x | colsum dy): split partials -> slab arena -> flat gradient."""
@@ -186,7 +195,7 @@ class LayoutEngine:
         n_slabs = lib.vlg_linear_wgrad_slabs(M, N, K)
         s = self._stream()
         self._timed("gemm_wgrad" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_wgrad", ptr(dy), N, ptr(x),
-                    K, ptr(self.slabs), stride, M, N, K, s)
+                    K, ptr(self.slabs), stride, M, N, K, self.gemm_flags, s, nbytes=4.0 * (M * N + M * K + n_slabs * stride))
         off = self.layout[wname][0]
         call("vlg_reduce_slabs", ptr(self.slabs), stride, n_slabs, self.grads.data_ptr() + 4 * off, stride, s)
 
@@ -333,8 +342,8 @@ class KernelTimer:
         self.only = only           # None = every family, else a tuple of family names to bracket
 
     class _Section:
-        def __init__(self, timer, family, flops):
-            self.t, self.family, self.flops = timer, family, flops
+        def __init__(self, timer, family, flops, nbytes=0.0):
+            self.t, self.family, self.flops, self.nbytes = timer, family, flops, nbytes
 
         def __enter__(self):
             self.s = torch.cuda.Event(enable_timing=True)
@@ -343,17 +352,18 @@ class KernelTimer:
 
         def __exit__(self, *a):
             self.e.record()
-            self.t.records.setdefault(self.family, []).append((self.s, self.e, self.flops))
+            self.t.records.setdefault(self.family, []).append((self.s, self.e, self.flops, self.nbytes))
 
-    def section(self, family: str, flops: float):
-        return KernelTimer._Section(self, family, flops)
+    def section(self, family: str, flops: float, nbytes: float = 0.0):
+        return KernelTimer._Section(self, family, flops, nbytes)
 
     def summary(self):
         """family -> {launches, avg_ms, total_ms, flops_per_launch} (call after a device sync)."""
         out = {}
         for fam, recs in self.records.items():
-            ms = [s.elapsed_time(e) for s, e, _ in recs]
-            fl = [f for _, _, f in recs]
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            fl = [f for _, _, f, _ in recs]
+            nb = [b for _, _, _, b in recs]
             out[fam] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms),
-                        "flops_per_launch": sum(fl) / len(fl)}
+                        "flops_per_launch": sum(fl) / len(fl), "bytes_per_launch": sum(nb) / len(nb)}
         return out

@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvlg_hip.so")
 
-EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU = 0, 1, 2, 4, 8
+EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_BF16 = 0, 1, 2, 4, 8, 16
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 
@@ -30,7 +30,7 @@ SIGNATURES = {
     "vlg_linear_fwd": (I, [P, I, P, I, P, P, I, P, P, L, I, I, I, P]),
     "vlg_linear_dgrad": (I, [P, I, P, I, P, I, P, L, I, I, I, P]),
     "vlg_linear_wgrad_slabs": (I, [L, I, I]),
-    "vlg_linear_wgrad": (I, [P, I, P, I, P, L, L, I, I, P]),
+    "vlg_linear_wgrad": (I, [P, I, P, I, P, L, L, I, I, I, P]),
     "vlg_attention_fwd": (I, [P, P, L, I, I, P]),
     "vlg_attention_bwd": (I, [P, P, P, L, I, I, P]),
     "vlg_layout_loss_scratch": (I, []),
