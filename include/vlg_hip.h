@@ -191,6 +191,14 @@ int vlg_fill_coords(float* dst, int b, int H, int W, int cp, int coord_c0, void*
 /* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True), modules.py:50, on padded NHWC */
 int vlg_upsample2x_fwd(const float* in, float* out, int b, int h, int w, int cp, void* stream);
 int vlg_upsample2x_bwd(const float* dout, float* din, int b, int h, int w, int cp, int accumulate, void* stream);
+/* Frozen HED edge detector, forward only (reference src/models/hned.py:9-105; used at trainer.py:190-192,216).
+ * 3x3 convs reuse vlg_conv3x3_fwd with prelu_slope pointing at 0.0 (ReLU, applied by the consumer on load). */
+int vlg_maxpool2x2(const float* in, float* out, int b, int h, int w, int cp, void* stream);            /* hned.py:20,28,38,48 */
+int vlg_score1x1_relu(const float* in, const float* w, const float* bias, float* out, int b, int H, int W,
+                      int C, int cp, void* stream);                                                    /* hned.py:60-64,90-94 */
+int vlg_hed_head(const float* s0, const float* s1, const float* s2, const float* s3, const float* s4,
+                 const float* combine_w, const float* combine_b, float* out /* (6,b,H,W) */, int b, int H, int W,
+                 void* stream);                                                                        /* hned.py:96-105 */
 /* dst = src (+ dst): gradient hand-over along the residual sums of gridnet.py:51-56 */
 int vlg_add_rows(float* dst, const float* src, int64_t n, int accumulate, void* stream);
 /* sums a vector of per-block partials into dst[0] (PReLU slope gradients); accumulate != 0 adds to dst */

@@ -21,6 +21,9 @@ Sources of each fixture (reference file:line):
                             gradient and EVERY parameter gradient under loss = sum(seg*r1) + sum(img*r2).
   gridnet_full64.npz        models.GridNet(10) (real widths 32/64/96) on (1,10,64,64): outputs, dx, seven parameter
                             gradients, all PReLU-slope gradients, |grad| sums of every tensor.
+  hned.npz                  models.HNED() (reference src/models/hned.py:9-105) with oracle.hned_spec.test_params weights
+                            (the trained ones are at an author-local path, trainer.py:97) on (1,3,64,64) and (2,3,32,48)
+                            inputs: all six outputs (d1..d5, fuse).
   coordgridnet_256.npz      models.CoordGridNet(10, filters_level=[8,16,24]) on (1,10,256,256) (the only size the
                             reference accepts): img, seg crop + checksums, dx crop, lateral_in / up_05 gradients.
                             Parameters in all three come from oracle.gridnet_spec.test_params (name-seeded), so
@@ -186,6 +189,21 @@ def main():
     finally:
         torch.Tensor.cuda = orig_cuda
     np.savez_compressed(os.path.join(OUT, "coordgridnet_256.npz"), **rec)
+
+    # ---- HED edge detector (frozen, forward only): reference module with name-seeded weights
+    from oracle import hned_spec as HS
+    hed = ref_models.HNED()
+    hp = HS.test_params(seed=0)
+    assert list(hed.state_dict().keys()) == list(hp.keys())
+    hed.load_state_dict(hp)
+    rec = {}
+    for tag, shape, sd_ in (("a", (1, 3, 64, 64), 6), ("b", (2, 3, 32, 48), 7)):
+        x = torch.rand(shape, generator=torch.Generator().manual_seed(sd_))
+        with torch.no_grad():
+            outs = hed(x)
+        rec[tag + "_x"] = x.numpy()
+        rec[tag + "_out"] = torch.stack([o[:, 0] for o in outs]).numpy()        # (6, b, H, W)
+    np.savez_compressed(os.path.join(OUT, "hned.npz"), **rec)
 
     torch.manual_seed(0)
     gn = ref_models.GridNet(10)

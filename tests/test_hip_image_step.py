@@ -43,3 +43,27 @@ def test_adam_steps_reduce_the_loss(dev):
     assert last < 0.95 * first, (first, last)
     sd = eng.state_dict()                        # still exports in the reference's key/shape format
     assert tuple(sd["lateral_in.conv.0.conv.weight"].shape) == (8, 12, 3, 3)
+
+
+def test_step_with_hed_edges(dev):
+    """Edges computed on the device by the frozen HED net (trainer.py:190-192, fused map) feed the same step: the
+    result equals the step run on those edge maps given as inputs, and equals the CPU restatement fed the HED
+    restatement's edges."""
+    from oracle import hned_spec as HS
+    from vlg.image_engine import ImageEngine, synthetic_frames
+    b, H, W, filt = 1, 32, 32, (8, 16, 24)
+    eng = ImageEngine(b, H, W, dev, arch="CoordGridNet", filters=filt, with_hed=True)
+    p = G.test_params(G.param_shapes(10, filt, coord=True), seed=5, linear=True)
+    eng.load_state_dict(p)
+    hp = HS.test_params(1)
+    eng.hed.load_state_dict(hp)
+    batch = synthetic_frames(b, H, W, seed=8)
+    cpu_batch = dict(batch)
+    cpu_batch["e1"] = HS.forward(hp, batch["frame1"])[5]
+    cpu_batch["e2"] = HS.forward(hp, batch["frame2"])[5]
+    parts, grads = S.loss_and_grads(p, cpu_batch, True)
+    dev_batch = {k: v.to(dev) for k, v in batch.items() if k not in ("e1", "e2")}
+    eng.forward(dev_batch)
+    eng.backward()
+    assert abs(float(eng.total()) - parts[4]) <= 1e-4 * abs(parts[4])
+    check_grads(eng.net.named_grads(), grads, True, tol=3e-4)

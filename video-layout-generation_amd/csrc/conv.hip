@@ -291,8 +291,7 @@ static bool conv_ok(const void* p) { return p != nullptr && vlg_aligned16(p); }
 extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bias, float* out, const float* resid,
                                const float* rowmask, const float* prelu_slope, const int* rowtab, int64_t rows_out,
                                int cin_p, int cout, int cout_p, int wp_in, int act_ch, int epilogue, void* stream) {
-    if (rows_out < 1 || cin_p < 32 || (cin_p & 31) || cout < 1 || cout > cout_p || (cout_p & 31) || cout_p > 128)
-        return VLG_ERR_SHAPE;
+    if (rows_out < 1 || cin_p < 32 || (cin_p & 31) || cout < 1 || cout > cout_p || (cout_p & 31)) return VLG_ERR_SHAPE;
     if (!conv_ok(in) || !conv_ok(w) || !conv_ok(out)) return VLG_ERR_ALIGN;
     if ((epilogue & VLG_CEPI_RESID) && !resid) return VLG_ERR_SHAPE;
     ConvArgs g{};

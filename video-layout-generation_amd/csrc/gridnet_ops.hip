@@ -142,6 +142,103 @@ __global__ __launch_bounds__(GO_BLOCK) void add_rows_kernel(float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------- HED helpers
+// (frozen edge detector, reference src/models/hned.py:9-105; forward only)
+// MaxPool2d(2,2) on padded NHWC, hned.py:20,28,38,48.  ReLU commutes with max, so the pool runs on the
+// pre-activation tensor and the consumer applies the ReLU on load.
+__global__ __launch_bounds__(GO_BLOCK) void maxpool2x2_kernel(const float* __restrict__ in, float* __restrict__ out, int b, int h,
+                                                             int w, int cp) {
+    const int H = 2 * h, W = 2 * w, c4n = cp >> 2;
+    const int64_t total = (int64_t)b * h * w * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GO_BLOCK) {
+        const int c = (int)(i % c4n) << 2;
+        const int x = (int)((i / c4n) % w);
+        const int y = (int)((i / ((int64_t)c4n * w)) % h);
+        const int64_t n = i / ((int64_t)c4n * w * h);
+        const float* p = in + ((n * (H + 2) + 2 * y + 1) * (int64_t)(W + 2) + 2 * x + 1) * cp + c;
+        const float4 a = ld4(p), bq = ld4(p + cp), cq = ld4(p + (int64_t)(W + 2) * cp), d = ld4(p + (int64_t)(W + 3) * cp);
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, bq.x), fmaxf(cq.x, d.x)); m.y = fmaxf(fmaxf(a.y, bq.y), fmaxf(cq.y, d.y));
+        m.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(cq.z, d.z)); m.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(cq.w, d.w));
+        st4(out + ((n * (h + 2) + y + 1) * (int64_t)(w + 2) + x + 1) * cp + c, m);
+    }
+}
+
+// 1x1 score convolution C -> 1 on relu(x) (hned.py:60-64, 90-94): one wavefront per pixel, shuffle reduction
+__global__ __launch_bounds__(GO_BLOCK) void score1x1_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int b,
+                                                           int H, int W, int C, int cp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * GO_BLOCK + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * GO_BLOCK) >> 6;
+    const int64_t total = (int64_t)b * H * W;
+    for (int64_t i = wave; i < total; i += nw) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int64_t n = i / ((int64_t)W * H);
+        const float* p = in + ((n * (H + 2) + y + 1) * (int64_t)(W + 2) + x + 1) * cp;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += fmaxf(p[c], 0.f) * w[c];
+        s = wave_sum(s);
+        if (lane == 0) out[i] = s + bias[0];
+    }
+}
+
+// F.interpolate(size=(H,W), mode='bilinear', align_corners=False) source index (ATen area_pixel_compute_source_index)
+__device__ __forceinline__ float hed_sample(const float* __restrict__ m, int h, int w, int Y, int X, float sy, float sx) {
+    float fy = sy * ((float)Y + 0.5f) - 0.5f, fx = sx * ((float)X + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    return (1.f - ly) * ((1.f - lx) * m[y0 * w + x0] + lx * m[y0 * w + x1]) + ly * ((1.f - lx) * m[y1 * w + x0] + lx * m[y1 * w + x1]);
+}
+
+// five score maps (levels 0..4 at H>>k) -> d1..d5 = sigmoid(upsampled score), fuse = sigmoid(1x1 conv over the five)
+// (hned.py:96-103); out is (6, b, H, W)
+__global__ __launch_bounds__(GO_BLOCK) void hed_head_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                           const float* __restrict__ s2, const float* __restrict__ s3,
+                                                           const float* __restrict__ s4, const float* __restrict__ cw,
+                                                           const float* __restrict__ cb, float* __restrict__ out, int b, int H,
+                                                           int W) {
+    const float* maps[5] = {s0, s1, s2, s3, s4};
+    const int64_t hw = (int64_t)H * W, total = (int64_t)b * hw;
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GO_BLOCK) {
+        const int X = (int)(i % W), Y = (int)((i / W) % H);
+        const int64_t n = i / hw;
+        float f = cb[0];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int h = H >> k, w = W >> k;
+            const float v = k == 0 ? maps[0][i] : hed_sample(maps[k] + n * h * w, h, w, Y, X, (float)h / (float)H, (float)w / (float)W);
+            out[(int64_t)k * total + i] = 1.f / (1.f + expf(-v));
+            f += cw[k] * v;
+        }
+        out[5 * total + i] = 1.f / (1.f + expf(-f));
+    }
+}
+
+extern "C" int vlg_maxpool2x2(const float* in, float* out, int b, int h, int w, int cp, void* stream) {
+    if (b < 1 || h < 1 || w < 1 || (cp & 3)) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(in) || !vlg_aligned16(out)) return VLG_ERR_ALIGN;
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(go_blocks((int64_t)b * h * w * (cp / 4))), dim3(GO_BLOCK), 0, (hipStream_t)stream, in, out, b, h, w, cp);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_score1x1_relu(const float* in, const float* w, const float* bias, float* out, int b, int H, int W, int C,
+                                 int cp, void* stream) {
+    if (b < 1 || H < 1 || W < 1 || C < 1 || C > cp) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL(score1x1_kernel, dim3(go_blocks((int64_t)b * H * W * 64)), dim3(GO_BLOCK), 0, (hipStream_t)stream, in, w, bias, out, b, H, W, C, cp);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_hed_head(const float* s0, const float* s1, const float* s2, const float* s3, const float* s4,
+                            const float* combine_w, const float* combine_b, float* out, int b, int H, int W, void* stream) {
+    if (b < 1 || H < 16 || W < 16 || (H & 15) || (W & 15)) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL(hed_head_kernel, dim3(go_blocks((int64_t)b * H * W)), dim3(GO_BLOCK), 0, (hipStream_t)stream, s0, s1, s2, s3, s4, combine_w, combine_b, out, b, H, W);
+    return vlg_last_error();
+}
+
 extern "C" int vlg_add_rows(float* dst, const float* src, int64_t n, int accumulate, void* stream) {
     if (n < 4 || (n & 3)) return VLG_ERR_SHAPE;
     if (!vlg_aligned16(dst) || !vlg_aligned16(src)) return VLG_ERR_ALIGN;

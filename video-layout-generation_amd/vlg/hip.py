@@ -54,6 +54,9 @@ SIGNATURES = {
     "vlg_fill_coords": (I, [P, I, I, I, I, I, P]),
     "vlg_upsample2x_fwd": (I, [P, P, I, I, I, I, P]),
     "vlg_upsample2x_bwd": (I, [P, P, I, I, I, I, I, P]),
+    "vlg_maxpool2x2": (I, [P, P, I, I, I, I, P]),
+    "vlg_score1x1_relu": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vlg_hed_head": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "vlg_add_rows": (I, [P, P, L, I, P]),
     "vlg_sum_partials": (I, [P, I, P, I, P]),
 }

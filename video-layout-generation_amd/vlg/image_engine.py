@@ -9,8 +9,10 @@ Appendix A, every piece a HIP kernel of libvlg_hip.so:
     loss = 40 L1(img, frame3) + 20 (GradientLoss + SsimLoss)(img, frame3) + 10 CE(seg, seg3)    (:248-251)
     backward; Adam(lr, betas=(beta1, 0.999))                   (:257-258)  analytic gradients, vlg_adam_step
 
-Deviations, stated: (1) the edge maps e1/e2 are INPUTS - the reference computes them with a frozen HED whose
-weights sit at an author-local path (trainer.py:97; Appendix A-2/A-3), so they cannot be reproduced;
+Deviations, stated: (1) the edge maps e1/e2 are inputs, OR - with with_hed=True - the fused output [5] of the
+frozen HED net run on frame1 / frame2 under no-grad exactly as trainer.py:190-192 intends (Appendix A-3); that
+net (vlg/hned.py) is complete, but its trained weights sit at an author-local path (trainer.py:97, A-2), so
+unless a checkpoint is loaded into engine.hed the edges come from whatever weights it was given;
 (2) the VGG term of CombinedLoss (loss.py:29-49) is left out - it needs torchvision's downloaded VGG19 weights
 (parity unpinned); (3) gradients are overwritten each step (A-5).
 """
@@ -32,12 +34,16 @@ W_L1, W_STYLE, W_CE = 40.0, 20.0, 10.0          # reference src/trainer.py:248-2
 
 class ImageEngine:
     def __init__(self, batch: int, H: int, W: int, device, arch: str = "CoordGridNet", lr: float = ADAM_LR,
-                 beta1: float = ADAM_BETA1, filters=(32, 64, 96)):
+                 beta1: float = ADAM_BETA1, filters=(32, 64, 96), with_hed: bool = False):
         if arch not in ("GridNet", "CoordGridNet"):
             raise ValueError("arch must be GridNet or CoordGridNet (reference src/main.py:101-102)")
         self.device, self.lr, self.beta1 = device, float(lr), float(beta1)
         self.b, self.H, self.W = batch, H, W
         self.net = GridNetHIP(10, batch, H, W, device, coord=(arch == "CoordGridNet"), filters=filters)
+        self.hed = None
+        if with_hed:
+            from .hned import HNEDHIP
+            self.hed = HNEDHIP(batch, H, W, device)
         n = self.net.params.numel()
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=device)
@@ -68,6 +74,10 @@ class ImageEngine:
 
     def forward(self, batch: Dict[str, torch.Tensor], flip: bool = False, want_grads: bool = True) -> torch.Tensor:
         """Forward + losses (+ d loss / d outputs).  Returns the device scalar-array {l1, gd, ssim, ce}."""
+        if self.hed is not None and "e1" not in batch:           # trainer.py:190-192, fused map = output [5]
+            batch = dict(batch)
+            batch["e1"] = self.hed.forward(batch["frame1"])[5].unsqueeze(1).contiguous()
+            batch["e2"] = self.hed.forward(batch["frame2"])[5].unsqueeze(1).contiguous()
         for k in IMAGE_KEYS:
             t = batch[k]
             if not t.is_cuda or not t.is_contiguous():
