@@ -86,13 +86,15 @@ def test_three_adam_steps_track_oracle(dev):
     assert checked > 0.5 * eng.n_params
 
 
-def test_full_size_properties(dev):
-    """BASELINE.json configs[1] at full size (32 x 16 x 32, d=256): too slow for the CPU oracle in a
-    unit test, so check size-independent properties: determinism (bitwise: no atomics anywhere),
+@pytest.mark.parametrize("shape", [dict(B=32, T=16, N=32, d=256), dict(B=8, T=32, N=64, d=512), dict(B=32, T=16, N=64, d=256)])
+def test_full_size_properties(dev, shape):
+    """BASELINE.json configs[1] at full size (32 x 16 x 32, d=256), one GPU's shard of configs[3] (64 clips of
+    32 x 64, d=512 over 8 GPUs = 8 per GPU) and the metric shape (32,16,64,256): too slow for the CPU oracle in
+    a unit test, so check size-independent properties: determinism (bitwise: no atomics anywhere),
     clip-permutation equivariance of per-clip outputs, and loss decrease over Adam steps."""
     from vlg.spec import LayoutConfig
     from vlg.data import synthetic_clips, to_device
-    cfg = LayoutConfig(B=32, T=16, N=32, d=256, n_layers=4)
+    cfg = LayoutConfig(n_layers=4, **shape)
     from vlg.engine import LayoutEngine
     eng = LayoutEngine(cfg, dev)
     clips = synthetic_clips(cfg.B, cfg.T, cfg.N, seed=3)

@@ -19,7 +19,6 @@ while time.time() - t0 < 2.0:
         run()
     torch.cuda.synchronize()
 probe = torch.zeros(2 * 512, dtype=torch.int64, device=dev)
-lib.vlg_debug_set_clock_probe.argtypes = [ctypes.c_void_p]
 lib.vlg_debug_set_clock_probe(probe.data_ptr())
 for _ in range(20):
     run()

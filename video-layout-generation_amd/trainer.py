@@ -135,16 +135,17 @@ class _ImageModel:
         arch = args.arch if args.arch in ("GridNet", "CoordGridNet") else "CoordGridNet"
         self.engine = ImageEngine(batch, size, size, self.device, arch=arch, lr=float(getattr(args, "lr", ADAM_LR)),
                                   beta1=float(getattr(args, "beta1", ADAM_BETA1)))
-        torch.manual_seed(int(getattr(args, "seed", SEED)))          # same init on every rank (main.py:57-60)
+        # torch's default initialisers for Conv2d (U(+-1/sqrt(fan_in)) for weight and bias) and PReLU (0.25), from one
+        # generator seeded like every rank's (main.py:57-60) so replicas start identical without a broadcast
+        g = torch.Generator().manual_seed(int(getattr(args, "seed", SEED)))
+        shapes = self.engine.net.reference_shapes()
         sd = {}
-        for k, shp in self.engine.net.reference_shapes().items():    # torch defaults: kaiming-uniform convs, slope 0.25
-            if len(shp) == 4:
-                bound = 1.0 / (shp[1] * 9) ** 0.5
-                sd[k] = (torch.rand(shp) * 2 - 1) * bound
-            elif shp == (1,):
+        for k, shp in shapes.items():
+            if shp == (1,):
                 sd[k] = torch.full(shp, 0.25)
             else:
-                sd[k] = (torch.rand(shp) * 2 - 1) * (1.0 / (self.engine.net.reference_shapes()[k[:-4] + "weight"][1] * 9) ** 0.5)
+                fan_in = (shp[1] if len(shp) == 4 else shapes[k[:-len("bias")] + "weight"][1]) * 9
+                sd[k] = (torch.rand(shp, generator=g) * 2 - 1) / fan_in ** 0.5
         self.engine.load_state_dict(sd)
         self.world = max(int(getattr(args, "gpus", 1) or 1), 1)
         self.step_count = 0

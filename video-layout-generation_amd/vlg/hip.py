@@ -21,6 +21,7 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "vlg_abi_version": (I, []),
     "vlg_build_arch": (c_char_p, []),
+    "vlg_debug_set_clock_probe": (None, [P]),
     "vlg_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "vlg_embed_bwd_slabs": (I, []),
     "vlg_embed_bwd": (I, [P, P, P, P, L, I, I, I, I, I, P]),
