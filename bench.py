@@ -113,9 +113,10 @@ def main():
     eng = LayoutEngine(cfg, dev, seed=SEED, precision="bf16" if args.dtype == "bf16" else "fp32")   # same seed on every rank (main.py:57-60)
     batch = to_device(synthetic_clips(cfg.B, cfg.T, cfg.N, seed=SEED + rank), dev)   # each rank its own clips
     reducer = None
-    if distributed:
+    force = os.environ.get("VLG_FORCE_COMM", "0") == "1"      # 1-GPU rehearsal of the RCCL path (torchrun, world size 1)
+    if world > 1 or (distributed and force):
         reducer = GradReducer(eng.grads_ext, bucket_ranges(eng.layout, eng.n_params, cfg.n_layers),
-                              always_communicate=True)
+                              always_communicate=force)
 
     def sync_all():
         torch.cuda.synchronize()

@@ -123,34 +123,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
     };
+    // One iteration: MFMAs of the tile in LDS buffer `cur`; in the middle, the register-resident tile kt+1 goes to the
+    // other LDS buffer and the registers are refilled with tile kt+DEPTH (DEPTH tiles travel global -> register at once).
     auto mainloop = [&](auto guard_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;
-        if (nk > 0) {
-            TA::template gload<GUARD>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid);
-            TB::template gload<GUARD>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
-            TA::sstore(ra, As0, tid);
-            TB::sstore(rb, Bs0, tid);
-        }
-        if (nk > 1) {
-            TA::template gload<GUARD>(ra, g.A, g.lda, m0, g.M, kbeg + BK, kend, tid);
-            TB::template gload<GUARD>(rb, g.B, g.ldb, n0, g.N, kbeg + BK, kend, tid);
-        }
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
+        constexpr int DEPTH = BF16 ? 2 : 1;      // bf16 MFMAs are 16x faster: the loop is load-latency bound, so keep
+                                                 // two tiles in flight per block (128 KB per CU) instead of one
+        float4 ra1[TA::NV], rb1[TB::NV];         // second register stage (DEPTH == 2 only)
+        auto load = [&](float4 (&xa)[TA::NV], float4 (&xb)[TB::NV], int t) {
+            const int64_t k0 = kbeg + (int64_t)t * BK;
+            TA::template gload<GUARD>(xa, g.A, g.lda, m0, g.M, k0, kend, tid);
+            TB::template gload<GUARD>(xb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+        };
+        auto iter = [&](int kt, float4 (&xa)[TA::NV], float4 (&xb)[TB::NV]) {
             const int cur = kt & 1;
             const float* as = As0 + cur * TA::FLOATS;
             const float* bs = Bs0 + cur * TB::FLOATS;
 #pragma unroll
             for (int s = 0; s < NCH / 2; ++s) chunk(as, bs, s);
             if (kt + 1 < nk) {
-                TA::sstore(ra, As0 + (cur ^ 1) * TA::FLOATS, tid);
-                TB::sstore(rb, Bs0 + (cur ^ 1) * TB::FLOATS, tid);
+                TA::sstore(xa, As0 + (cur ^ 1) * TA::FLOATS, tid);
+                TB::sstore(xb, Bs0 + (cur ^ 1) * TB::FLOATS, tid);
             }
-            if (kt + 2 < nk) {
-                const int64_t k0 = kbeg + (int64_t)(kt + 2) * BK;
-                TA::template gload<GUARD>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
-                TB::template gload<GUARD>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
-            }
+            if (kt + 1 + DEPTH < nk) load(xa, xb, kt + 1 + DEPTH);
 #pragma unroll
             for (int s = NCH / 2; s < NCH; ++s) chunk(as, bs, s);
             if constexpr (COLSUM) {
@@ -161,6 +156,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
                 }
             }
             __syncthreads();
+        };
+        if (nk > 0) {
+            load(ra, rb, 0);
+            TA::sstore(ra, As0, tid);
+            TB::sstore(rb, Bs0, tid);
+        }
+        if (nk > 1) load(ra, rb, 1);
+        if constexpr (DEPTH == 2) {
+            if (nk > 2) load(ra1, rb1, 2);
+        }
+        __syncthreads();
+        if constexpr (DEPTH == 1) {
+            for (int kt = 0; kt < nk; ++kt) iter(kt, ra, rb);
+        } else {
+            for (int kt = 0; kt < nk; kt += 2) {          // tile kt+1 is in (ra, rb) on even, in (ra1, rb1) on odd iterations
+                iter(kt, ra, rb);
+                if (kt + 1 < nk) iter(kt + 1, ra1, rb1);
+            }
         }
     };
     // interior blocks (every tile fully inside both operands) take the unguarded instantiation
