@@ -71,16 +71,23 @@ class OracleEngine:
             reducer.ready("embed")
         return self.loss_out
 
-    def adam_step(self, grad_scale: float = 1.0):
-        self.step_count += 1
-        O.adam_step(self.params, self.grads * grad_scale, self.exp_avg, self.exp_avg_sq, self.step_count,
-                    lr=self.lr, beta1=self.beta1, beta2=ADAM_BETA2, eps=ADAM_EPS)
+    def adam_step(self, grad_scale: float = 1.0, lo: int = 0, hi=None, advance: bool = True):
+        hi = self.n_params if hi is None else hi
+        if advance:
+            self.step_count += 1
+        O.adam_step(self.params[lo:hi], self.grads[lo:hi] * grad_scale, self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                    self.step_count, lr=self.lr, beta1=self.beta1, beta2=ADAM_BETA2, eps=ADAM_EPS)
 
     def train_step(self, batch, reducer=None):
+        """Same schedule as LayoutEngine.train_step: everything but the embedding range is updated while the last
+        bucket's all-reduce is still in flight."""
         loss = self.forward_backward(batch, reducer)
         if reducer is not None:
+            split = self.layout["l0.ln1_g"][0]
+            reducer.wait(keep=("embed",))
+            self.adam_step(reducer.grad_scale, lo=split, hi=self.n_params)
             reducer.wait()
-            self.adam_step(reducer.grad_scale)
+            self.adam_step(reducer.grad_scale, lo=0, hi=split, advance=False)
         else:
             self.adam_step()
         return loss

@@ -66,13 +66,18 @@ class GradReducer:
         if self.world == 1 and not self.always:
             return
         s, e = self.buckets[tag]
-        self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.pending.append((tag, dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
-    def wait(self) -> None:
-        """Make the current stream wait for every outstanding bucket (no host sync on RCCL)."""
-        for w in self.pending:
-            w.wait()
-        self.pending.clear()
+    def wait(self, keep=()) -> None:
+        """Make the current stream wait for every outstanding bucket (no host sync on RCCL), except the tags in
+        `keep`, which stay in flight (the optimiser can update the finished ranges meanwhile)."""
+        rest = []
+        for tag, w in self.pending:
+            if tag in keep:
+                rest.append((tag, w))
+            else:
+                w.wait()
+        self.pending = rest
 
 
 def all_reduce_mean_(tensors, world: int, group=None) -> None:

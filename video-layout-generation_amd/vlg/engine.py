@@ -310,18 +310,28 @@ class LayoutEngine:
         Returns the loss scalars (summed over ranks when a reducer is attached)."""
         loss = self.forward_backward(batch, reducer)
         if reducer is not None:
+            # the embedding bucket is the last to be produced, so its all-reduce would be fully exposed: update
+            # everything else while it is in flight, then the embedding range
+            split = self.layout["l0.ln1_g"][0]
+            reducer.wait(keep=("embed",))
+            self.adam_step(reducer.grad_scale, lo=split, hi=self.n_params)
             reducer.wait()
-            self.adam_step(reducer.grad_scale)
+            self.adam_step(reducer.grad_scale, lo=0, hi=split, advance=False)
         else:
             self.adam_step()
         return loss
 
     # ------------------------------------------------------------------- optimiser
-    def adam_step(self, grad_scale: float = 1.0) -> None:
-        """torch.optim.Adam(lr, betas=(beta1, 0.999)) on the flat buffer (reference src/trainer.py:83,258)."""
-        self.step_count += 1
-        call("vlg_adam_step", ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-             self.n_params, self.step_count, self.lr, self.beta1, ADAM_BETA2, ADAM_EPS, grad_scale, self._stream())
+    def adam_step(self, grad_scale: float = 1.0, lo: int = 0, hi: Optional[int] = None, advance: bool = True) -> None:
+        """torch.optim.Adam(lr, betas=(beta1, 0.999)) on the flat buffer (reference src/trainer.py:83,258), or on its
+        [lo, hi) slice (both multiples of 4); `advance` = False keeps the step count (second slice of one step)."""
+        hi = self.n_params if hi is None else hi
+        if advance:
+            self.step_count += 1
+        o = 4 * lo
+        call("vlg_adam_step", self.params.data_ptr() + o, self.grads.data_ptr() + o, self.exp_avg.data_ptr() + o,
+             self.exp_avg_sq.data_ptr() + o, hi - lo, self.step_count, self.lr, self.beta1, ADAM_BETA2, ADAM_EPS,
+             grad_scale, self._stream())
 
     # ---------------------------------------------------------------- public views
     def outputs_btn(self) -> tuple:
