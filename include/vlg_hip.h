@@ -203,6 +203,11 @@ int vlg_score1x1_relu(const float* in, const float* w, const float* bias, float*
 int vlg_hed_head(const float* s0, const float* s1, const float* s2, const float* s3, const float* s4,
                  const float* combine_w, const float* combine_b, float* out /* (6,b,H,W) */, int b, int H, int W,
                  void* stream);                                                                        /* hned.py:96-105 */
+/* VggLoss (reference src/loss.py:29-49): frozen VGG19 features[:27] on both images, L1 mean of the relu4_4 features.
+ * The trunk reuses vlg_conv3x3_fwd / _dgrad (ReLU = slope 0) and vlg_maxpool2x2; these two close the loop. */
+int vlg_maxpool2x2_bwd(const float* in, const float* dout, float* din, int b, int h, int w, int cp, void* stream);
+int vlg_l1_relu_padded(const float* a, const float* b, float* da, float* loss, float* scratch /* >= 4096 */,
+                       int64_t rows, int cp, int64_t count, float grad_scale, void* stream);
 /* dst = src (+ dst): gradient hand-over along the residual sums of gridnet.py:51-56 */
 int vlg_add_rows(float* dst, const float* src, int64_t n, int accumulate, void* stream);
 /* sums a vector of per-block partials into dst[0] (PReLU slope gradients); accumulate != 0 adds to dst */

@@ -32,7 +32,7 @@ def ssim_loss(x, y):                                        # reference src/loss
     return sum(one(x[:, i], y[:, i]) for i in range(x.size()[1]))
 
 
-def step_losses(p, batch, coord, flip=False):
+def step_losses(p, batch, coord, flip=False, vgg_params=None):
     img_mean = torch.tensor([0.485, 0.456, 0.406])[None, :, None, None]        # trainer.py:123
     img_std = torch.tensor([0.229, 0.224, 0.225])[None, :, None, None]         # trainer.py:122
     mean_arr = torch.tensor([-0.03, -0.088, -0.188])[None, :, None, None]      # trainer.py:120
@@ -49,11 +49,15 @@ def step_losses(p, batch, coord, flip=False):
     l1 = F.l1_loss(img, f3)                                                     # :248 (x40 below)
     gd, ss = gradient_loss(img, f3), ssim_loss(img, f3)                         # :249 CombinedLoss without VGG
     ce = F.cross_entropy(seg, seg3)                                             # :250
-    return l1, gd, ss, ce, 40 * l1 + 20 * (gd + ss) + 10 * ce                  # :251
+    style = gd + ss
+    if vgg_params is not None:                                                  # CombinedLoss = vgg + gd + ssim, loss.py:61-62
+        from oracle import vgg_spec
+        style = style + vgg_spec.vgg_loss(vgg_params, img, f3)
+    return l1, gd, ss, ce, 40 * l1 + 20 * style + 10 * ce                      # :251
 
 
-def loss_and_grads(p, batch, coord, flip=False):
+def loss_and_grads(p, batch, coord, flip=False, vgg_params=None):
     q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    parts = step_losses(q, batch, coord, flip)
+    parts = step_losses(q, batch, coord, flip, vgg_params)
     parts[4].backward()
     return [float(v.detach()) for v in parts], {k: v.grad for k, v in q.items()}

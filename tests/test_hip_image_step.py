@@ -67,3 +67,22 @@ def test_step_with_hed_edges(dev):
     eng.backward()
     assert abs(float(eng.total()) - parts[4]) <= 1e-4 * abs(parts[4])
     check_grads(eng.net.named_grads(), grads, True, tol=3e-4)
+
+
+def test_step_with_full_combined_loss(dev):
+    """CombinedLoss = VGG + GradientLoss + SSIM (reference src/loss.py:61-62) in the step; the VGG term under
+    name-seeded frozen weights (parity unpinned against the reference for that term, see tests/test_hip_vgg.py)."""
+    from oracle import vgg_spec as V
+    from vlg.image_engine import ImageEngine, synthetic_frames
+    b, H, W, filt = 1, 32, 32, (8, 16, 24)
+    eng = ImageEngine(b, H, W, dev, arch="GridNet", filters=filt, with_vgg=True)
+    p = G.test_params(G.param_shapes(10, filt), seed=5, linear=True)
+    eng.load_state_dict(p)
+    vp = V.test_params(2)
+    eng.vgg.load_state_dict(vp)
+    batch = synthetic_frames(b, H, W, seed=4)
+    parts, grads = S.loss_and_grads(p, batch, False, vgg_params=vp)
+    eng.forward({k: v.to(dev) for k, v in batch.items()})
+    eng.backward()
+    assert abs(float(eng.total()) - parts[4]) <= 1e-4 * abs(parts[4]), (float(eng.total()), parts[4])
+    check_grads(eng.net.named_grads(), grads, False)          # ReLU trunk of the VGG term: kink-tolerant bound

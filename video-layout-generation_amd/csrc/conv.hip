@@ -309,7 +309,7 @@ extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bia
 }
 
 extern "C" int vlg_conv3x3_dgrad_slabs(int64_t rows_in, int cin_p) {
-    const int bn = cin_p;                                   // one column tile (cin_p <= 128)
+    const int bn = cin_p <= 128 ? cin_p : 128;              // one column tile up to 128 channels, 128-wide tiles beyond
     return (int)((rows_in + 127) / 128) * ((cin_p + bn - 1) / bn);
 }
 
@@ -319,7 +319,8 @@ extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, 
                                  int wp, int act_ch, int epilogue, void* stream) {
     // din[p, ci] = mask[p] * sum_tap sum_co dout[p - shift(tap), co] * W[co][tap][ci]   (stride 1)
     // stride 2: tap_tables[tap][p] = output row feeding input row p through that tap (or a zero guard row)
-    if (rows_in < 1 || cin_p < 32 || (cin_p & 31) || cin_p > 128 || cout_p < 32 || (cout_p & 31)) return VLG_ERR_SHAPE;
+    if (rows_in < 1 || cin_p < 32 || (cin_p & 31) || (cin_p > 128 && (cin_p & 127)) || cout_p < 32 || (cout_p & 31))
+        return VLG_ERR_SHAPE;                                // wide inputs are tiled 128 columns at a time
     if (!conv_ok(dout) || !conv_ok(w) || !conv_ok(din)) return VLG_ERR_ALIGN;
     if ((epilogue & VLG_CEPI_DPRELU) && (!x_in || !prelu_slope)) return VLG_ERR_SHAPE;
     ConvArgs g{};

@@ -7,6 +7,9 @@
 
 #define GO_BLOCK 256
 
+__global__ void scale_scalar_kernel(float* v, float s) { v[0] *= s; }
+__global__ void sum_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ dst, int accumulate);
+
 static unsigned go_blocks(int64_t n) {
     int64_t b = (n + GO_BLOCK - 1) / GO_BLOCK;
     return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -216,6 +219,89 @@ __global__ __launch_bounds__(GO_BLOCK) void hed_head_kernel(const float* __restr
         }
         out[5 * total + i] = 1.f / (1.f + expf(-f));
     }
+}
+
+// backward of the 2x2 max-pool: the gradient of a pooled pixel goes to the first maximum of its window in
+// row-major order (torch's tie rule); thread per (input pixel, float4 of channels), gather form
+__global__ __launch_bounds__(GO_BLOCK) void maxpool2x2_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                                 float* __restrict__ din, int b, int h, int w, int cp) {
+    const int H = 2 * h, W = 2 * w, c4n = cp >> 2;
+    const int64_t total = (int64_t)b * h * w * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GO_BLOCK) {
+        const int c = (int)(i % c4n) << 2;
+        const int x = (int)((i / c4n) % w);
+        const int y = (int)((i / ((int64_t)c4n * w)) % h);
+        const int64_t n = i / ((int64_t)c4n * w * h);
+        const int64_t base = ((n * (H + 2) + 2 * y + 1) * (int64_t)(W + 2) + 2 * x + 1) * cp + c;
+        const int64_t offs[4] = {0, cp, (int64_t)(W + 2) * cp, (int64_t)(W + 3) * cp};
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ld4(in + base + offs[k]);
+        const float4 g = ld4(dout + ((n * (h + 2) + y + 1) * (int64_t)(w + 2) + x + 1) * cp + c);
+        const float* gp = &g.x;
+        float4 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = f4_zero();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int best = 0;
+            float bv = (&v[0].x)[e];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float t = (&v[k].x)[e];
+                if (t > bv) { bv = t; best = k; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) (&o[k].x)[e] = (k == best) ? gp[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st4(din + base + offs[k], o[k]);
+    }
+}
+
+// mean |relu(a) - relu(b)| over C channels of the interior pixels of two padded tensors, and its gradient with respect
+// to the PRE-activation a (VggLoss.forward, reference src/loss.py:43-49: features end in relu4_4)
+__global__ __launch_bounds__(GO_BLOCK) void l1_relu_padded_kernel(const float* __restrict__ a, const float* __restrict__ bq,
+                                                                 float* __restrict__ da, float* __restrict__ part, int64_t n4,
+                                                                 float gscale) {
+    __shared__ float red[GO_BLOCK / 64];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * GO_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * GO_BLOCK) {
+        const float4 x = ld4(a + 4 * i), y = ld4(bq + 4 * i);
+        const float* xp = &x.x; const float* yp = &y.x;
+        float4 g;
+        float* gp = &g.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = fmaxf(xp[e], 0.f) - fmaxf(yp[e], 0.f);
+            acc += fabsf(d);
+            gp[e] = xp[e] > 0.f ? (d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f)) : 0.f;
+        }
+        if (da != nullptr) st4(da + 4 * i, g);
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+extern "C" int vlg_maxpool2x2_bwd(const float* in, const float* dout, float* din, int b, int h, int w, int cp, void* stream) {
+    if (b < 1 || h < 1 || w < 1 || (cp & 3)) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(in) || !vlg_aligned16(dout) || !vlg_aligned16(din)) return VLG_ERR_ALIGN;
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(go_blocks((int64_t)b * h * w * (cp / 4))), dim3(GO_BLOCK), 0, (hipStream_t)stream, in, dout, din, b, h, w, cp);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_l1_relu_padded(const float* a, const float* b_, float* da, float* loss, float* scratch, int64_t rows, int cp,
+                                  int64_t count, float grad_scale, void* stream) {
+    // scratch >= 4096 floats; `count` = number of real elements (b*C*H*W) the mean is taken over
+    if (rows < 1 || cp < 4 || (cp & 3) || count < 1) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(a) || !vlg_aligned16(b_) || (da && !vlg_aligned16(da))) return VLG_ERR_ALIGN;
+    const int64_t n4 = rows * cp / 4;
+    const unsigned blocks = go_blocks(n4);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(l1_relu_padded_kernel, dim3(blocks), dim3(GO_BLOCK), 0, s, a, b_, da, scratch, n4, grad_scale / (float)count);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(GO_BLOCK), 0, s, scratch, (int)blocks, loss, 0);
+    hipLaunchKernelGGL(scale_scalar_kernel, dim3(1), dim3(1), 0, s, loss, 1.0f / (float)count);
+    return vlg_last_error();
 }
 
 extern "C" int vlg_maxpool2x2(const float* in, float* out, int b, int h, int w, int cp, void* stream) {

@@ -58,6 +58,8 @@ SIGNATURES = {
     "vlg_maxpool2x2": (I, [P, P, I, I, I, I, P]),
     "vlg_score1x1_relu": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vlg_hed_head": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    "vlg_maxpool2x2_bwd": (I, [P, P, P, I, I, I, I, P]),
+    "vlg_l1_relu_padded": (I, [P, P, P, P, P, L, I, L, F, P]),
     "vlg_add_rows": (I, [P, P, L, I, P]),
     "vlg_sum_partials": (I, [P, I, P, I, P]),
 }

@@ -13,8 +13,10 @@ Deviations, stated: (1) the edge maps e1/e2 are inputs, OR - with with_hed=True 
 frozen HED net run on frame1 / frame2 under no-grad exactly as trainer.py:190-192 intends (Appendix A-3); that
 net (vlg/hned.py) is complete, but its trained weights sit at an author-local path (trainer.py:97, A-2), so
 unless a checkpoint is loaded into engine.hed the edges come from whatever weights it was given;
-(2) the VGG term of CombinedLoss (loss.py:29-49) is left out - it needs torchvision's downloaded VGG19 weights
-(parity unpinned); (3) gradients are overwritten each step (A-5).
+(2) the VGG term of CombinedLoss (loss.py:29-49, 61-62) is included with with_vgg=True (vlg/vgg_loss.py) - its
+arithmetic is complete, but torchvision's ImageNet weights are a download (parity unpinned), so
+unless real weights are loaded into engine.vgg it is a perceptual loss under whatever frozen weights it was given;
+(3) gradients are overwritten each step (A-5).
 """
 from __future__ import annotations
 
@@ -34,12 +36,16 @@ W_L1, W_STYLE, W_CE = 40.0, 20.0, 10.0          # reference src/trainer.py:248-2
 
 class ImageEngine:
     def __init__(self, batch: int, H: int, W: int, device, arch: str = "CoordGridNet", lr: float = ADAM_LR,
-                 beta1: float = ADAM_BETA1, filters=(32, 64, 96), with_hed: bool = False):
+                 beta1: float = ADAM_BETA1, filters=(32, 64, 96), with_hed: bool = False, with_vgg: bool = False):
         if arch not in ("GridNet", "CoordGridNet"):
             raise ValueError("arch must be GridNet or CoordGridNet (reference src/main.py:101-102)")
         self.device, self.lr, self.beta1 = device, float(lr), float(beta1)
         self.b, self.H, self.W = batch, H, W
         self.net = GridNetHIP(10, batch, H, W, device, coord=(arch == "CoordGridNet"), filters=filters)
+        self.vgg = None
+        if with_vgg:
+            from .vgg_loss import VggLossHIP
+            self.vgg = VggLossHIP(batch, H, W, device)
         self.hed = None
         if with_hed:
             from .hned import HNEDHIP
@@ -57,7 +63,7 @@ class ImageEngine:
         self.dtmp = torch.empty(batch, 3, H, W, **f32)
         self.dseg = torch.empty(batch, 20, H, W, **f32)
         self.scratch = torch.zeros(hip.load().vlg_image_loss_scratch(), **f32)
-        self.losses = torch.zeros(4, **f32)          # {l1, gradient, ssim, ce}
+        self.losses = torch.zeros(8, **f32)          # {l1, gradient, ssim, ce, vgg, -, -, -}
         arr = ctypes.c_float * 3
         self._mean, self._istd = arr(*OUT_MEAN), arr(*[1.0 / s for s in OUT_STD])
         self._zero = arr(0.0, 0.0, 0.0)
@@ -99,12 +105,17 @@ class ImageEngine:
         if want_grads:
             call("vlg_add_rows", ptr(self.dimg), ptr(self.dtmp), self.dimg.numel(), 1, s)
         call("vlg_ce_nchw", ptr(self.seg), ptr(self.seg3), g(self.dseg), L.data_ptr() + 12, sc, b, 20, H * W, W_CE, s)
+        if self.vgg is not None:                       # CombinedLoss = vgg + gd + ssim, x20 (loss.py:61-62, trainer.py:249)
+            lv, dv = self.vgg.loss_and_grad(self.img, self.f3, grad_scale=W_STYLE, want_grad=want_grads)
+            L[4:5].copy_(lv)
+            if want_grads:
+                call("vlg_add_rows", ptr(self.dimg), ptr(dv), self.dimg.numel(), 1, s)
         return self.losses
 
     def total(self) -> torch.Tensor:
-        """40 L1 + 20 (GD + SSIM) + 10 CE   (reference src/trainer.py:248-251 without the VGG term)."""
+        """40 L1 + 20 (VGG + GD + SSIM) + 10 CE   (reference src/trainer.py:248-251; the VGG slot is 0 without with_vgg)."""
         L = self.losses
-        return W_L1 * L[0] + W_STYLE * (L[1] + L[2]) + W_CE * L[3]
+        return W_L1 * L[0] + W_STYLE * (L[1] + L[2] + L[4]) + W_CE * L[3]
 
     def backward(self) -> None:
         b, H, W, s = self.b, self.H, self.W, self._stream()
