@@ -53,7 +53,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     constexpr int BK = 32;
     constexpr bool A_KC = MODE != CONV_WGRAD;
     constexpr bool B_KC = MODE == CONV_FWD;
-    constexpr int WM = (BM == 32) ? 1 : ((BN == 128 || BN == 64) ? 2 : 4);
+    constexpr int WM = (BM == 32) ? 1 : (BM == 64 ? 2 : ((BN == 128 || BN == 64) ? 2 : 4));
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     static_assert(TM >= 1 && TN >= 1 && TM * 32 * WM == BM && TN * 32 * WN == BN, "tile / wave layout");
@@ -286,6 +286,9 @@ static void fill_shifts(ConvArgs& g, int wp, int sign) {
         for (int kx = 0; kx < 3; ++kx) g.shift[ky * 3 + kx] = sign * ((ky - 1) * wp + (kx - 1));
 }
 
+// fewer 128-row blocks than 1.5 per CU: use 64-row tiles instead (twice the blocks, same LDS budget per CU)
+static bool few_blocks(int64_t rows, int tiles_n) { return ((rows + 127) / 128) * tiles_n < 384; }
+
 static bool conv_ok(const void* p) { return p != nullptr && vlg_aligned16(p); }
 
 extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bias, float* out, const float* resid,
@@ -303,14 +306,19 @@ extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bia
     fill_shifts(g, wp_in, rowtab ? 1 : 1);
     hipStream_t s = (hipStream_t)stream;
     if (cout_p == 32) return launch_conv<CONV_FWD, 128, 32>(g, s);
-    if (cout_p == 64) return launch_conv<CONV_FWD, 128, 64>(g, s);
     if (cout_p == 96) return launch_conv<CONV_FWD, 128, 96>(g, s);
-    return launch_conv<CONV_FWD, 128, 128>(g, s);
+    // small grids (coarse levels, small batches) would leave CUs idle with 128-row tiles: halve the tile height
+    const bool small = few_blocks(rows_out, cout_p == 64 ? 1 : (cout + 127) / 128);
+    if (cout_p == 64) return small ? launch_conv<CONV_FWD, 64, 64>(g, s) : launch_conv<CONV_FWD, 128, 64>(g, s);
+    return small ? launch_conv<CONV_FWD, 64, 128>(g, s) : launch_conv<CONV_FWD, 128, 128>(g, s);
 }
 
 extern "C" int vlg_conv3x3_dgrad_slabs(int64_t rows_in, int cin_p) {
     const int bn = cin_p <= 128 ? cin_p : 128;              // one column tile up to 128 channels, 128-wide tiles beyond
-    return (int)((rows_in + 127) / 128) * ((cin_p + bn - 1) / bn);
+    const int tiles_n = (cin_p + bn - 1) / bn;
+    const bool half = (cin_p == 64 || cin_p >= 128) && few_blocks(rows_in, tiles_n);
+    const int bm = half ? 64 : 128;
+    return (int)((rows_in + bm - 1) / bm) * tiles_n;
 }
 
 extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, const float* x_in,
@@ -333,9 +341,10 @@ extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, 
     else fill_shifts(g, wp, -1);
     hipStream_t s = (hipStream_t)stream;
     if (cin_p == 32) return launch_conv<CONV_DGRAD, 128, 32>(g, s);
-    if (cin_p == 64) return launch_conv<CONV_DGRAD, 128, 64>(g, s);
     if (cin_p == 96) return launch_conv<CONV_DGRAD, 128, 96>(g, s);
-    return launch_conv<CONV_DGRAD, 128, 128>(g, s);
+    const bool small = few_blocks(rows_in, cin_p == 64 ? 1 : (cin_p + 127) / 128);
+    if (cin_p == 64) return small ? launch_conv<CONV_DGRAD, 64, 64>(g, s) : launch_conv<CONV_DGRAD, 128, 64>(g, s);
+    return small ? launch_conv<CONV_DGRAD, 64, 128>(g, s) : launch_conv<CONV_DGRAD, 128, 128>(g, s);
 }
 
 static void conv_wgrad_plan(int64_t rows, int cin_p, int cout_p, int* splits, int64_t* per) {

@@ -16,7 +16,8 @@
 #define IMG_MAX_BLOCKS 1024
 #define IMG_MAX_TILES 65536
 // scratch (floats): [0] = normaliser, [1] = spare, [4 ..) per-block partial sums (SSIM: one per tile)
-#define IMG_SCRATCH (4 + IMG_MAX_TILES)
+#define IMG_SCRATCH (4 + IMG_MAX_TILES + IMG_MAX_BLOCKS)      // + per-block counts of scored targets (cross entropy)
+#define IMG_COUNT_OFF (4 + IMG_MAX_TILES)
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
@@ -36,22 +37,34 @@ static unsigned img_blocks(int64_t n) {
 }
 
 // ------------------------------------------------------------------ cross entropy, NCHW
+// scored-target counts (target != ignore_index -100), one partial per block; every block of the main kernel sums the
+// partials itself, so no single-block pass over the whole target map sits on the critical path
 __global__ __launch_bounds__(IMG_BLOCK) void ce_count_kernel(const int64_t* __restrict__ target, int64_t n,
                                                              float* __restrict__ scratch) {
     __shared__ float red[IMG_BLOCK / 64];
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += IMG_BLOCK) s += (target[i] != -100) ? 1.f : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IMG_BLOCK)
+        s += (target[i] != -100) ? 1.f : 0.f;
     s = block_sum(s, red);
-    if (threadIdx.x == 0) scratch[0] = 1.0f / fmaxf(s, 1.0f);
+    if (threadIdx.x == 0) scratch[IMG_COUNT_OFF + blockIdx.x] = s;       // counts are integers < 2^24: exact in fp32
 }
 
 // one thread per pixel; class c of pixel p sits at logits[(n*C + c)*hw + p] (coalesced per class)
 __global__ __launch_bounds__(IMG_BLOCK) void ce_nchw_kernel(const float* __restrict__ logits,
                                                             const int64_t* __restrict__ target,
                                                             float* __restrict__ dlogits, float* __restrict__ scratch,
-                                                            int64_t npix, int C, int64_t hw, float grad_scale) {
+                                                            int64_t npix, int C, int64_t hw, float grad_scale,
+                                                            int n_count_blocks) {
     __shared__ float red[IMG_BLOCK / 64];
-    const float inv_cnt = scratch[0];
+    __shared__ float s_inv;
+    {
+        float c = 0.f;
+        for (int i = threadIdx.x; i < n_count_blocks; i += IMG_BLOCK) c += scratch[IMG_COUNT_OFF + i];
+        c = block_sum(c, red);
+        if (threadIdx.x == 0) s_inv = 1.0f / fmaxf(c, 1.0f);
+        __syncthreads();
+    }
+    const float inv_cnt = s_inv;
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x; i < npix; i += (int64_t)gridDim.x * IMG_BLOCK) {
         const int64_t n = i / hw, p = i - n * hw;
@@ -290,9 +303,9 @@ extern "C" int vlg_ce_nchw(const float* logits, const int64_t* target, float* dl
     hipStream_t s = (hipStream_t)stream;
     const int64_t npix = (int64_t)b * hw;
     const unsigned blocks = img_blocks(npix);
-    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(IMG_BLOCK), 0, s, target, npix, scratch);
+    hipLaunchKernelGGL(ce_count_kernel, dim3(blocks), dim3(IMG_BLOCK), 0, s, target, npix, scratch);
     hipLaunchKernelGGL(ce_nchw_kernel, dim3(blocks), dim3(IMG_BLOCK), 0, s, logits, target, dlogits, scratch, npix, C,
-                       hw, grad_scale);
+                       hw, grad_scale, (int)blocks);
     hipLaunchKernelGGL(img_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, (int)blocks, 1.0f, loss);
     return vlg_last_error();
 }
