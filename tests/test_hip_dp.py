@@ -1,0 +1,68 @@
+"""GPU, two processes sharing the one MI355X of the test box, gloo as transport (RCCL refuses two ranks on one
+device): the REAL engine - HIP kernels, bucket hooks fired from backward, the split Adam that overlaps the last
+bucket - must reproduce one process stepping on the union batch.  The multi-GPU RCCL run itself is the driver's;
+bench.py rehearses the RCCL code path at world size 1 (VLG_FORCE_COMM=1)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+CFG = dict(B=2, T=8, N=8, d=64, n_layers=2)
+
+
+def _worker(rank, world, port, out):
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, world_size=world, rank=rank)
+    from oracle import layout_spec as O
+    from vlg.dp import GradReducer, bucket_ranges
+    from vlg.engine import LayoutEngine
+    from vlg.spec import LayoutConfig
+    dev = torch.device("cuda:0")
+    cfg = LayoutConfig(**CFG)
+    eng = LayoutEngine(cfg, dev, seed=1024)
+    red = GradReducer(eng.grads_ext, bucket_ranges(eng.layout, eng.n_params, cfg.n_layers))
+    losses = []
+    for step in range(2):
+        full = O.synthetic_batch(cfg.B * world, cfg.T, cfg.N, seed=60 + step)
+        mine = {k: v[rank::world].contiguous().to(dev) for k, v in full.items()}
+        loss = eng.train_step(mine, red)
+        losses.append(float(loss[0]) / world)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"params": eng.params.cpu(), "losses": losses}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_match_one_big_batch(dev, tmp_path):
+    world, out = 2, str(tmp_path / "dp.pt")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=True)
+    from oracle import layout_spec as O
+    from vlg.engine import LayoutEngine
+    from vlg.spec import ADAM_LR, LayoutConfig
+    cfg = LayoutConfig(**dict(CFG, B=CFG["B"] * world))
+    eng = LayoutEngine(cfg, dev, seed=1024)
+    signal = torch.ones(eng.n_params, dtype=torch.bool)
+    for step in range(2):
+        full = O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=60 + step)
+        loss = float(eng.train_step({k: v.to(dev) for k, v in full.items()})[0])
+        assert abs(got["losses"][step] - loss) <= 1e-4 * abs(loss)
+        g = eng.grads.cpu()
+        signal &= g.abs() > 1e-3 * float(g.abs().max())
+    p = eng.params.cpu()
+    # elements with a real gradient agree; zero-gradient ones (key bias) get +-lr of rounding noise from Adam
+    assert torch.allclose(got["params"][signal], p[signal], rtol=1e-4, atol=1e-6)
+    assert float((got["params"] - p).abs().max()) <= 2 * 2 * ADAM_LR * 1.01
