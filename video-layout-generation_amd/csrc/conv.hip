@@ -19,6 +19,7 @@
 // one of gemm.hip (gemm_tile.h).
 #include "gemm_tile.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define CONV_FWD 0
 #define CONV_DGRAD 1
@@ -48,9 +49,10 @@ __device__ __forceinline__ float4 prelu4(float4 v, float a, int c, int act_ch) {
                        c + 2 < act_ch ? prelu_f(v.z, a) : v.z, c + 3 < act_ch ? prelu_f(v.w, a) : v.w);
 }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, int BK>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvArgs g) {
-    constexpr int BK = 32;
+    constexpr int NCH = BK / 8;                            // 8-deep MFMA chunks per K tile
+    constexpr int KPR = BK / 4;                            // float4 per K-contiguous tile row
     constexpr bool A_KC = MODE != CONV_WGRAD;
     constexpr bool B_KC = MODE == CONV_FWD;
     constexpr int WM = (BM == 32) ? 1 : (BM == 64 ? 2 : ((BN == 128 || BN == 64) ? 2 : 4));
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     if constexpr (MODE != CONV_WGRAD) {
 #pragma unroll
         for (int i = 0; i < TA::NV; ++i) {
-            int64_t r = m0 + ((tid + GEMM_THREADS * i) >> 3);
+            int64_t r = m0 + ((tid + GEMM_THREADS * i) / KPR);
             arow[i] = r < g.M ? r : g.M - 1;                   // rows past M are computed but never stored
         }
         if (g.rowtab != nullptr && g.tab_stride == 0) {
@@ -133,21 +135,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             const int tap = (int)(k0 / g.cin);
             const int ci0 = (int)(k0 - (int64_t)tap * g.cin);
             const int64_t sh = g.shift[tap];
-            ach = ci0 + ((tid & 7) << 2);
+            ach = ci0 + ((tid % KPR) << 2);
 #pragma unroll
             for (int i = 0; i < TA::NV; ++i) {
                 int64_t r = arow[i];
                 if (g.tab_stride != 0) r = g.rowtab[(int64_t)tap * g.tab_stride + r];
-                ra[i] = ld4(g.A + (r + sh) * g.lda + ci0 + (((tid + GEMM_THREADS * i) & 7) << 2));
+                ra[i] = ld4(g.A + (r + sh) * g.lda + ci0 + (((tid + GEMM_THREADS * i) % KPR) << 2));
             }
             if constexpr (MODE == CONV_FWD) {
 #pragma unroll
                 for (int i = 0; i < TB::NV; ++i) {
                     const int idx = tid + GEMM_THREADS * i;
                     if (TB::F4 % GEMM_THREADS != 0 && idx >= TB::F4) { rb[i] = f4_zero(); continue; }
-                    int row = n0 + (idx >> 3);
+                    int row = n0 + idx / KPR;
                     row = row < g.N ? row : g.N - 1;
-                    rb[i] = ld4(g.B + (int64_t)row * g.ldb + k0 + ((idx & 7) << 2));
+                    rb[i] = ld4(g.B + (int64_t)row * g.ldb + k0 + ((idx % KPR) << 2));
                 }
             } else {
 #pragma unroll
@@ -209,12 +211,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
         const int cur = kt & 1;
         const float* as = As0 + cur * TA::FLOATS;
         const float* bs = Bs0 + cur * TB::FLOATS;
-        chunk(as, bs, 0);
-        chunk(as, bs, 1);
+#pragma unroll
+        for (int c = 0; c < NCH / 2; ++c) chunk(as, bs, c);
         if (kt + 1 < nk) sstore(cur ^ 1);
         if (kt + 2 < nk) gload(kbeg + (int64_t)(kt + 2) * BK);
-        chunk(as, bs, 2);
-        chunk(as, bs, 3);
+#pragma unroll
+        for (int c = NCH / 2; c < NCH; ++c) chunk(as, bs, c);
         if constexpr (MODE == CONV_WGRAD) {
             if (tn == 0 && tid < BM) {                          // bias gradient: column sums of the dOut tile
 #pragma unroll 8
@@ -271,13 +273,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     }
 }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, int BK = 32>
 static int launch_conv(ConvArgs g, hipStream_t s) {
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (g.N + BN - 1) / BN;
     const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.splits;
     if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN>), dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, s, g);
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, BK>), dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, s, g);
     return vlg_last_error();
 }
 
@@ -286,8 +288,23 @@ static void fill_shifts(ConvArgs& g, int wp, int sign) {
         for (int kx = 0; kx < 3; ++kx) g.shift[ky * 3 + kx] = sign * ((ky - 1) * wp + (kx - 1));
 }
 
-// fewer 128-row blocks than 1.5 per CU: use 64-row tiles instead (twice the blocks, same LDS budget per CU)
-static bool few_blocks(int64_t rows, int tiles_n) { return ((rows + 127) / 128) * tiles_n < 384; }
+// development switch: VLG_CONV_NARROW_BK=16|32 selects the K-tile depth of the 32-channel tiles
+static int conv_narrow_bk() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VLG_CONV_NARROW_BK"); v = e ? atoi(e) : 16; }   // 16: +2.7 % on CoordGridNet b=4 256x256 (more blocks per CU)
+    return v;
+}
+
+// Tile choice at small batch / coarse levels.  Blocks on one CU share its MFMA pipes, so a launch takes about
+// max-blocks-per-CU x (work of one block): 529 blocks of 128 rows cost 3 units on 256 CUs, 1057 blocks of 64 rows
+// cost 5 half-units.  Prefer the finer tiling whenever it lowers that bound by more than the efficiency it loses.
+static int64_t cu_units(int64_t blocks) { return (blocks + 255) / 256; }
+static bool few_blocks(int64_t rows, int tiles_n) {
+    const int64_t b128 = ((rows + 127) / 128) * tiles_n, b64 = ((rows + 63) / 64) * tiles_n;
+    return b128 < 384 || 10 * cu_units(b64) < 17 * cu_units(b128);      // half-size blocks: 2*u128 vs u64, keep a 15 % margin
+}
+// 96 output channels as three 32-wide column tiles when there are too few row tiles to fill the chip
+static bool split_96(int64_t rows) { return (rows + 127) / 128 < 400; }
 
 static bool conv_ok(const void* p) { return p != nullptr && vlg_aligned16(p); }
 
@@ -305,8 +322,8 @@ extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bia
     g.splits = 1; g.kc_per_split = g.Kc; g.epi = epilogue & ~VLG_CEPI_DPRELU; g.act_ch = act_ch;
     fill_shifts(g, wp_in, rowtab ? 1 : 1);
     hipStream_t s = (hipStream_t)stream;
-    if (cout_p == 32) return launch_conv<CONV_FWD, 128, 32>(g, s);
-    if (cout_p == 96) return launch_conv<CONV_FWD, 128, 96>(g, s);
+    if (cout_p == 32) return conv_narrow_bk() == 16 ? launch_conv<CONV_FWD, 128, 32, 16>(g, s) : launch_conv<CONV_FWD, 128, 32>(g, s);
+    if (cout_p == 96) return split_96(rows_out) ? launch_conv<CONV_FWD, 128, 32>(g, s) : launch_conv<CONV_FWD, 128, 96>(g, s);
     // small grids (coarse levels, small batches) would leave CUs idle with 128-row tiles: halve the tile height
     const bool small = few_blocks(rows_out, cout_p == 64 ? 1 : (cout + 127) / 128);
     if (cout_p == 64) return small ? launch_conv<CONV_FWD, 64, 64>(g, s) : launch_conv<CONV_FWD, 128, 64>(g, s);
@@ -314,7 +331,8 @@ extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bia
 }
 
 extern "C" int vlg_conv3x3_dgrad_slabs(int64_t rows_in, int cin_p) {
-    const int bn = cin_p <= 128 ? cin_p : 128;              // one column tile up to 128 channels, 128-wide tiles beyond
+    int bn = cin_p <= 128 ? cin_p : 128;                    // one column tile up to 128 channels, 128-wide tiles beyond
+    if (cin_p == 96 && split_96(rows_in)) bn = 32;
     const int tiles_n = (cin_p + bn - 1) / bn;
     const bool half = (cin_p == 64 || cin_p >= 128) && few_blocks(rows_in, tiles_n);
     const int bm = half ? 64 : 128;
@@ -340,8 +358,8 @@ extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, 
     if (tap_tables) { for (int t = 0; t < 9; ++t) g.shift[t] = 0; }
     else fill_shifts(g, wp, -1);
     hipStream_t s = (hipStream_t)stream;
-    if (cin_p == 32) return launch_conv<CONV_DGRAD, 128, 32>(g, s);
-    if (cin_p == 96) return launch_conv<CONV_DGRAD, 128, 96>(g, s);
+    if (cin_p == 32) return conv_narrow_bk() == 16 ? launch_conv<CONV_DGRAD, 128, 32, 16>(g, s) : launch_conv<CONV_DGRAD, 128, 32>(g, s);
+    if (cin_p == 96) return split_96(rows_in) ? launch_conv<CONV_DGRAD, 128, 32>(g, s) : launch_conv<CONV_DGRAD, 128, 96>(g, s);
     const bool small = few_blocks(rows_in, cin_p == 64 ? 1 : (cin_p + 127) / 128);
     if (cin_p == 64) return small ? launch_conv<CONV_DGRAD, 64, 64>(g, s) : launch_conv<CONV_DGRAD, 128, 64>(g, s);
     return small ? launch_conv<CONV_DGRAD, 64, 128>(g, s) : launch_conv<CONV_DGRAD, 128, 128>(g, s);
