@@ -100,24 +100,44 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
         bv[j] = (MODE == CONV_FWD && g.bias != nullptr) ? g.bias[col < g.N ? col : g.N - 1] : 0.f;
     }
 
-    // ---- per-thread constants of the gathers
-    // forward / data gradient: the rows of A this thread stages (fixed across K tiles)
-    int64_t arow[TA::NV];
+    // ---- per-thread constants of the gathers.  Everything that does not change from K tile to K tile is folded
+    // into per-thread base pointers here; a K tile then adds ONE wave-uniform offset (tap shift and channel block),
+    // which the scalar unit tracks with two running counters instead of a division per tile.
+    const float* pa[TA::NV];                                   // forward / data gradient: rows of A (fixed across K tiles)
+    const float* pb[TB::NV];
+    int arow[TA::NV];                                          // data gradient of a stride-2 conv: row -> per-tap table index
     if constexpr (MODE != CONV_WGRAD) {
 #pragma unroll
         for (int i = 0; i < TA::NV; ++i) {
             int64_t r = m0 + ((tid + GEMM_THREADS * i) / KPR);
-            arow[i] = r < g.M ? r : g.M - 1;                   // rows past M are computed but never stored
+            r = r < g.M ? r : g.M - 1;                         // rows past M are computed but never stored
+            arow[i] = (int)r;
+            if (g.rowtab != nullptr && g.tab_stride == 0) r = g.rowtab[r];
+            pa[i] = g.A + r * g.lda + (((tid + GEMM_THREADS * i) % KPR) << 2);
         }
-        if (g.rowtab != nullptr && g.tab_stride == 0) {
 #pragma unroll
-            for (int i = 0; i < TA::NV; ++i) arow[i] = g.rowtab[arow[i]];
+        for (int i = 0; i < TB::NV; ++i) {
+            const int idx = tid + GEMM_THREADS * i;
+            if constexpr (MODE == CONV_FWD) {
+                int row = n0 + idx / KPR;
+                row = row < g.N ? row : g.N - 1;
+                pb[i] = g.B + (int64_t)row * g.ldb + ((idx % KPR) << 2);
+            } else {
+                pb[i] = g.B + (int64_t)(idx / (BN / 4)) * g.ldb + n0 + ((idx % (BN / 4)) << 2);
+            }
         }
     }
     // weight gradient: the (tap, channel) of every B column this thread stages
     int64_t bcoloff[TB::NV];
     int bch[TB::NV];
+    float bslope[TB::NV];                                      // slope of this thread's four channels if they share one
+    const bool act_quad_uniform = (g.act_ch & 3) == 0;         // a float4 never straddles act_ch
     if constexpr (MODE == CONV_WGRAD) {
+#pragma unroll
+        for (int i = 0; i < TA::NV; ++i) {
+            const int idx = tid + GEMM_THREADS * i;
+            pa[i] = g.A + (int64_t)(idx / (BM / 4)) * g.lda + m0 + ((idx % (BM / 4)) << 2);
+        }
 #pragma unroll
         for (int i = 0; i < TB::NV; ++i) {
             int col = n0 + (((tid + GEMM_THREADS * i) % (BN / 4)) << 2);
@@ -125,61 +145,84 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             const int tap = col / g.cin;
             bcoloff[i] = (int64_t)g.shift[tap] * g.ldb + (col - tap * g.cin);
             bch[i] = col - tap * g.cin;
+            bslope[i] = bch[i] < g.act_ch ? slope : 1.0f;
+            pb[i] = g.B + (int64_t)((tid + GEMM_THREADS * i) / (BN / 4)) * g.ldb + bcoloff[i];
         }
     }
 
     float4 ra[TA::NV], rb[TB::NV];
+    (void)bslope; (void)act_quad_uniform; (void)arow;
     int ach = 0;                                              // first channel of this thread's float4 in the staged A tile
+    int ci_stage = 0;                                         // channel block of the staged A tile (wave-uniform)
+    int g_tap = (int)(kbeg / g.cin), g_ci = (int)(kbeg - (int64_t)g_tap * g.cin);   // (tap, channel) of the next gload
     auto gload = [&](int64_t k0) {
         if constexpr (MODE != CONV_WGRAD) {
-            const int tap = (int)(k0 / g.cin);
-            const int ci0 = (int)(k0 - (int64_t)tap * g.cin);
-            const int64_t sh = g.shift[tap];
+            const int tap = g_tap, ci0 = g_ci;
+            g_ci += BK;
+            if (g_ci >= g.cin) { g_ci = 0; ++g_tap; }
+            ci_stage = ci0;
             ach = ci0 + ((tid % KPR) << 2);
+            if (g.tab_stride != 0) {                           // per-tap row tables (data gradient of a stride-2 conv)
 #pragma unroll
-            for (int i = 0; i < TA::NV; ++i) {
-                int64_t r = arow[i];
-                if (g.tab_stride != 0) r = g.rowtab[(int64_t)tap * g.tab_stride + r];
-                ra[i] = ld4(g.A + (r + sh) * g.lda + ci0 + (((tid + GEMM_THREADS * i) % KPR) << 2));
-            }
-            if constexpr (MODE == CONV_FWD) {
-#pragma unroll
-                for (int i = 0; i < TB::NV; ++i) {
-                    const int idx = tid + GEMM_THREADS * i;
-                    if (TB::F4 % GEMM_THREADS != 0 && idx >= TB::F4) { rb[i] = f4_zero(); continue; }
-                    int row = n0 + idx / KPR;
-                    row = row < g.N ? row : g.N - 1;
-                    rb[i] = ld4(g.B + (int64_t)row * g.ldb + k0 + ((idx % KPR) << 2));
+                for (int i = 0; i < TA::NV; ++i) {
+                    const int64_t r = g.rowtab[(int64_t)tap * g.tab_stride + arow[i]];
+                    ra[i] = ld4(g.A + r * g.lda + ci0 + (((tid + GEMM_THREADS * i) % KPR) << 2));
                 }
             } else {
+                const int64_t off = (int64_t)g.shift[tap] * g.lda + ci0;
 #pragma unroll
-                for (int i = 0; i < TB::NV; ++i) {
-                    const int idx = tid + GEMM_THREADS * i;
-                    if (TB::F4 % GEMM_THREADS != 0 && idx >= TB::F4) { rb[i] = f4_zero(); continue; }
-                    const int co = ci0 + idx / (BN / 4);
-                    rb[i] = ld4(g.B + (int64_t)co * g.ldb + (int64_t)tap * g.b_tap_stride + n0 + ((idx % (BN / 4)) << 2));
-                }
+                for (int i = 0; i < TA::NV; ++i) ra[i] = ld4(pa[i] + off);
+            }
+            const int64_t boff = MODE == CONV_FWD ? k0 : (int64_t)ci0 * g.ldb + (int64_t)tap * g.b_tap_stride;
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) {
+                const int idx = tid + GEMM_THREADS * i;
+                if (TB::F4 % GEMM_THREADS != 0 && idx >= TB::F4) { rb[i] = f4_zero(); continue; }
+                rb[i] = ld4(pb[i] + boff);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < TA::NV; ++i) {
                 const int idx = tid + GEMM_THREADS * i;
                 if (TA::F4 % GEMM_THREADS != 0 && idx >= TA::F4) { ra[i] = f4_zero(); continue; }
-                ra[i] = ld4(g.A + (k0 + idx / (BM / 4)) * g.lda + m0 + ((idx % (BM / 4)) << 2));
+                ra[i] = ld4(pa[i] + k0 * g.lda);
             }
+            if (g.rowtab != nullptr) {
 #pragma unroll
-            for (int i = 0; i < TB::NV; ++i) {
-                int64_t kr = k0 + (tid + GEMM_THREADS * i) / (BN / 4);
-                if (g.rowtab != nullptr) kr = g.rowtab[kr];
-                rb[i] = ld4(g.B + kr * g.ldb + bcoloff[i]);
+                for (int i = 0; i < TB::NV; ++i) {
+                    const int64_t kr = g.rowtab[k0 + (tid + GEMM_THREADS * i) / (BN / 4)];
+                    rb[i] = ld4(g.B + kr * g.ldb + bcoloff[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TB::NV; ++i) rb[i] = ld4(pb[i] + k0 * g.ldb);
             }
         }
     };
+    const bool act_tile_uniform = (g.act_ch % BK) == 0;       // a K tile lies wholly below or above act_ch
     auto sstore = [&](int buf) {
         if (act_on_load) {
             if constexpr (MODE == CONV_FWD) {
+                if (act_tile_uniform) {
+                    if (ci_stage < g.act_ch) {
+                        if (slope == 0.f) {                    // ReLU (VGG / HED trunks)
 #pragma unroll
-                for (int i = 0; i < TA::NV; ++i) ra[i] = prelu4(ra[i], slope, ach, g.act_ch);
+                            for (int i = 0; i < TA::NV; ++i)
+                                ra[i] = make_float4(fmaxf(ra[i].x, 0.f), fmaxf(ra[i].y, 0.f), fmaxf(ra[i].z, 0.f), fmaxf(ra[i].w, 0.f));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < TA::NV; ++i)
+                                ra[i] = make_float4(prelu_f(ra[i].x, slope), prelu_f(ra[i].y, slope), prelu_f(ra[i].z, slope), prelu_f(ra[i].w, slope));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TA::NV; ++i) ra[i] = prelu4(ra[i], slope, ach, g.act_ch);
+                }
+            } else if (act_quad_uniform) {
+#pragma unroll
+                for (int i = 0; i < TB::NV; ++i)
+                    rb[i] = make_float4(prelu_f(rb[i].x, bslope[i]), prelu_f(rb[i].y, bslope[i]), prelu_f(rb[i].z, bslope[i]), prelu_f(rb[i].w, bslope[i]));
             } else {
 #pragma unroll
                 for (int i = 0; i < TB::NV; ++i) rb[i] = prelu4(rb[i], slope, bch[i], g.act_ch);
