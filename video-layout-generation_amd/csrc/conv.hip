@@ -43,10 +43,15 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
-// channels c .. c+3 of one pixel; channels >= act_ch (the AddCoords pair) are left linear
-__device__ __forceinline__ float4 prelu4(float4 v, float a, int c, int act_ch) {
-    return make_float4(c < act_ch ? prelu_f(v.x, a) : v.x, c + 1 < act_ch ? prelu_f(v.y, a) : v.y,
-                       c + 2 < act_ch ? prelu_f(v.z, a) : v.z, c + 3 < act_ch ? prelu_f(v.w, a) : v.w);
+// branch-free and exact: max(v,0) + a*min(v,0) is v for v > 0 and the singly-rounded a*v otherwise; a = 1 is the identity,
+// a = 0 is ReLU.  med3 keeps the compiler from inserting NaN-canonicalising moves around max/min.
+__device__ __forceinline__ float act_f(float v, float a) {
+    return __builtin_fmaf(a, __builtin_amdgcn_fmed3f(v, -__builtin_inff(), 0.f), __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()));
+}
+__device__ __forceinline__ float4 act4(float4 v, float4 a) { return make_float4(act_f(v.x, a.x), act_f(v.y, a.y), act_f(v.z, a.z), act_f(v.w, a.w)); }
+// slopes of channels c .. c+3: channels >= act_ch (the AddCoords pair, padding) stay linear
+__device__ __forceinline__ float4 slope4(float a, int c, int act_ch) {
+    return make_float4(c < act_ch ? a : 1.f, c + 1 < act_ch ? a : 1.f, c + 2 < act_ch ? a : 1.f, c + 3 < act_ch ? a : 1.f);
 }
 
 template <int MODE, int BM, int BN, int BK>
@@ -83,7 +88,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave - wm * WN;
     const float slope = g.prelu ? g.prelu[0] : 1.0f;          // slope 1 == identity
-    const bool act_on_load = g.prelu != nullptr && MODE != CONV_DGRAD;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -130,8 +134,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     // weight gradient: the (tap, channel) of every B column this thread stages
     int64_t bcoloff[TB::NV];
     int bch[TB::NV];
-    float bslope[TB::NV];                                      // slope of this thread's four channels if they share one
-    const bool act_quad_uniform = (g.act_ch & 3) == 0;         // a float4 never straddles act_ch
+    float4 bslope[TB::NV];                                     // slopes of this thread's four channels (fixed across K tiles)
     if constexpr (MODE == CONV_WGRAD) {
 #pragma unroll
         for (int i = 0; i < TA::NV; ++i) {
@@ -145,22 +148,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             const int tap = col / g.cin;
             bcoloff[i] = (int64_t)g.shift[tap] * g.ldb + (col - tap * g.cin);
             bch[i] = col - tap * g.cin;
-            bslope[i] = bch[i] < g.act_ch ? slope : 1.0f;
+            bslope[i] = slope4(slope, bch[i], g.act_ch);
             pb[i] = g.B + (int64_t)((tid + GEMM_THREADS * i) / (BN / 4)) * g.ldb + bcoloff[i];
         }
     }
 
     float4 ra[TA::NV], rb[TB::NV];
-    (void)bslope; (void)act_quad_uniform; (void)arow;
+    (void)bslope; (void)arow; (void)bch;
     int ach = 0;                                              // first channel of this thread's float4 in the staged A tile
-    int ci_stage = 0;                                         // channel block of the staged A tile (wave-uniform)
     int g_tap = (int)(kbeg / g.cin), g_ci = (int)(kbeg - (int64_t)g_tap * g.cin);   // (tap, channel) of the next gload
     auto gload = [&](int64_t k0) {
         if constexpr (MODE != CONV_WGRAD) {
             const int tap = g_tap, ci0 = g_ci;
             g_ci += BK;
             if (g_ci >= g.cin) { g_ci = 0; ++g_tap; }
-            ci_stage = ci0;
             ach = ci0 + ((tid % KPR) << 2);
             if (g.tab_stride != 0) {                           // per-tap row tables (data gradient of a stride-2 conv)
 #pragma unroll
@@ -199,34 +200,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             }
         }
     };
-    const bool act_tile_uniform = (g.act_ch % BK) == 0;       // a K tile lies wholly below or above act_ch
     auto sstore = [&](int buf) {
-        if (act_on_load) {
-            if constexpr (MODE == CONV_FWD) {
-                if (act_tile_uniform) {
-                    if (ci_stage < g.act_ch) {
-                        if (slope == 0.f) {                    // ReLU (VGG / HED trunks)
+        if constexpr (MODE == CONV_FWD) {
+            const float4 sl = slope4(slope, ach, g.act_ch);      // one float4 per thread and K tile: every staged row shares it
 #pragma unroll
-                            for (int i = 0; i < TA::NV; ++i)
-                                ra[i] = make_float4(fmaxf(ra[i].x, 0.f), fmaxf(ra[i].y, 0.f), fmaxf(ra[i].z, 0.f), fmaxf(ra[i].w, 0.f));
-                        } else {
+            for (int i = 0; i < TA::NV; ++i) ra[i] = act4(ra[i], sl);
+        } else if constexpr (MODE == CONV_WGRAD) {
 #pragma unroll
-                            for (int i = 0; i < TA::NV; ++i)
-                                ra[i] = make_float4(prelu_f(ra[i].x, slope), prelu_f(ra[i].y, slope), prelu_f(ra[i].z, slope), prelu_f(ra[i].w, slope));
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TA::NV; ++i) ra[i] = prelu4(ra[i], slope, ach, g.act_ch);
-                }
-            } else if (act_quad_uniform) {
-#pragma unroll
-                for (int i = 0; i < TB::NV; ++i)
-                    rb[i] = make_float4(prelu_f(rb[i].x, bslope[i]), prelu_f(rb[i].y, bslope[i]), prelu_f(rb[i].z, bslope[i]), prelu_f(rb[i].w, bslope[i]));
-            } else {
-#pragma unroll
-                for (int i = 0; i < TB::NV; ++i) rb[i] = prelu4(rb[i], slope, bch[i], g.act_ch);
-            }
+            for (int i = 0; i < TB::NV; ++i) rb[i] = act4(rb[i], bslope[i]);
         }
         TA::sstore(ra, As0 + buf * TA::FLOATS, tid);
         TB::sstore(rb, Bs0 + buf * TB::FLOATS, tid);
