@@ -37,6 +37,12 @@ KERNEL_OF_FAMILY = {             # rocprofv3 kernel names (profiles/) for each t
     "gemm_wgrad": "gemm_f32_kernel<128,128,32,false,false,0,true>",
     "gemm_head": "gemm_f32_kernel<128,32,32,..>/<32,128,32,..>",
 }
+KERNEL_OF_FAMILY_BF16 = {        # --dtype bf16: bf16 LDS tiles, 64-deep, IO = storage bits (csrc/gemm_bf16.hip)
+    "gemm_fwd": "gemm_bf16_kernel<128,128,true,true,*,false,IO>",
+    "gemm_dgrad": "gemm_bf16_kernel<128,128,true,false,*,false,IO>",
+    "gemm_wgrad": "gemm_bf16_kernel<128,128,false,false,0,true,IO>",
+    "gemm_head": "gemm_bf16_kernel<128,32,..>/<32,128,..>",
+}
 
 
 def cpu_baseline(cfg, budget_s: float = 12.0):
@@ -179,7 +185,7 @@ def main():
                     traffic = json.load(f).get(fam)
             bound, peak, unit = "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
             if args.dtype == "bf16":
-                # with 16x faster MFMAs the same kernel is bound by moving its fp32 operands: price it against HBM
+                # with 16x faster MFMAs the same kernel is bound by moving its operands: price it against HBM
                 # (algorithmic bytes: both operands once + the slabs written)
                 bound, peak, unit = "hbm", PEAK_HBM_GBS, "GB/s"
                 achieved = s["bytes_per_launch"] / (s["avg_ms"] * 1e-3) / 1e9
@@ -187,7 +193,7 @@ def main():
             roof = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(s["bytes_per_launch"]),
-                    "kernel": KERNEL_OF_FAMILY[fam], "launches": s["launches"],
+                    "kernel": (KERNEL_OF_FAMILY_BF16 if args.dtype == "bf16" else KERNEL_OF_FAMILY)[fam], "launches": s["launches"],
                     "avg_launch_us": round(1e3 * s["avg_ms"], 2),
                     "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
                     "share_of_step": round(s["total_ms"] / (1e3 * elapsed), 4),
@@ -208,8 +214,10 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / 10
             line["bf16_projections"] = {"value": round(cfg.B / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt, 4),
-                                        "note": "operands rounded to bf16 for v_mfma_f32_32x32x16_bf16, fp32 accumulate, "
-                                                "fp32 tensors; loss within 2e-2 of fp32 (tests/test_hip_step.py)",
+                                        "note": "v_mfma_f32_32x32x16_bf16 projections (fp32 accumulate) with the projection-side "
+                                                "activations and their gradients stored as bf16 in HBM; residual stream, "
+                                                "statistics, softmax, losses, weight gradients, Adam fp32; loss within 2e-2 "
+                                                "of fp32 (tests/test_hip_step.py)",
                                         "final_loss": round(float(e2.loss_out[0]), 5)}
             del e2
         if world == 1 and not args.no_cpu_baseline:

@@ -24,6 +24,8 @@
 
 #include <stdint.h>
 
+typedef uint16_t vlg_bf16;    /* bfloat16 bit pattern (activation storage of the bf16 mode) */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -60,11 +62,20 @@ int vlg_embed_bwd(const float* dx, const int64_t* slot_class, const float* slot_
 int vlg_layernorm_fwd(const float* x, const float* gamma, const float* beta,
                       float* y, float* mean, float* rstd,
                       int64_t rows, int d, float eps, void* stream);
+/* same, y written as bf16 (the normalised activation only feeds a projection in the bf16 mode) */
+int vlg_layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta,
+                           vlg_bf16* y, float* mean, float* rstd,
+                           int64_t rows, int d, float eps, void* stream);
 int vlg_layernorm_bwd_slabs(int64_t rows);
 int vlg_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                       const float* gamma, const float* dres, float* dx_out,
                       float* slabs, int64_t slab_stride,
                       int64_t rows, int d, void* stream);
+/* same, dy read as bf16 (it comes out of a projection's data gradient); x, dres, dx stay fp32 */
+int vlg_layernorm_bwd_bf16(const vlg_bf16* dy, const float* x, const float* mean, const float* rstd,
+                           const float* gamma, const float* dres, float* dx_out,
+                           float* slabs, int64_t slab_stride,
+                           int64_t rows, int d, void* stream);
 
 /* ------------------------------------------------------------------------ GEMM
  * fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs for the dense QKV/FFN/head projections.
@@ -81,16 +92,23 @@ int vlg_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
 #define VLG_EPI_DGELU  8   /* C = acc * gelu'(aux_in[row,col])                       */
 #define VLG_EPI_BF16   16  /* operands rounded to bf16 for v_mfma_f32_32x32x16_bf16, fp32 accumulate and fp32
                               tensors in HBM (BASELINE.json configs[2]); default is exact-fp32 MFMA  */
-int vlg_linear_fwd(const float* A, int lda, const float* W, int ldw, const float* bias,
-                   float* C, int ldc, const float* aux_in, float* aux_out,
+/* bf16 ACTIVATION STORAGE (with VLG_EPI_BF16 only): the activation operands named below are vlg_bf16 arrays in
+ * HBM instead of float - half the bytes of a mode that is HBM-bound.  Weights, biases, gradient slabs and the
+ * residual stream stay fp32; leading dimensions count elements.                                               */
+#define VLG_EPI_A_BF16   32   /* first operand (A of fwd, dY of dgrad / wgrad) is bf16                          */
+#define VLG_EPI_B_BF16   64   /* wgrad: X is bf16                                                               */
+#define VLG_EPI_OUT_BF16 128  /* C and the epilogue's auxiliary operands (aux_in, aux_out) are bf16             */
+int vlg_linear_fwd(const void* A, int lda, const float* W, int ldw, const float* bias,
+                   void* C, int ldc, const void* aux_in, void* aux_out,
                    int64_t M, int N, int K, int epilogue, void* stream);
-int vlg_linear_dgrad(const float* dY, int ldy, const float* W, int ldw,
-                     float* dX, int ldx, const float* aux_in,
+int vlg_linear_dgrad(const void* dY, int ldy, const float* W, int ldw,
+                     void* dX, int ldx, const void* aux_in,
                      int64_t M, int N, int K, int epilogue, void* stream);
-int vlg_linear_wgrad_slabs(int64_t M, int N, int K);
-int vlg_linear_wgrad(const float* dY, int ldy, const float* X, int ldx,
+int vlg_linear_wgrad_slabs(int64_t M, int N, int K);                 /* slab count of a flags = 0 launch */
+int vlg_linear_wgrad_slabs_for(int64_t M, int N, int K, int flags);  /* slab count of a launch with these flags */
+int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
                      float* slabs, int64_t slab_stride,
-                     int64_t M, int N, int K, int flags /* 0 or VLG_EPI_BF16 */, void* stream);
+                     int64_t M, int N, int K, int flags /* VLG_EPI_BF16 | storage bits */, void* stream);
 
 /* ------------------------------------------------------------------- attention
  * Temporal encoder core: causal softmax attention along T for each (clip, slot,
@@ -99,6 +117,10 @@ int vlg_linear_wgrad(const float* dY, int ldy, const float* X, int ldx,
 int vlg_attention_fwd(const float* qkv, float* o, int64_t n_seq, int T, int d, void* stream);
 int vlg_attention_bwd(const float* qkv, const float* dout, float* dqkv,
                       int64_t n_seq, int T, int d, void* stream);
+/* same with every tensor stored as bf16 (arithmetic stays fp32) */
+int vlg_attention_fwd_bf16(const vlg_bf16* qkv, vlg_bf16* o, int64_t n_seq, int T, int d, void* stream);
+int vlg_attention_bwd_bf16(const vlg_bf16* qkv, const vlg_bf16* dout, vlg_bf16* dqkv,
+                           int64_t n_seq, int T, int d, void* stream);
 
 /* ---------------------------------------------------------------------- losses
  * Fused softmax-cross-entropy + smooth-L1 + IoU, forward and backward in one pass.

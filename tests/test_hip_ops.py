@@ -262,3 +262,121 @@ def test_bad_arguments_raise(H, dev):
     with pytest.raises(H.HipError):
         H.call("vlg_linear_fwd", x.data_ptr() + 4, 64, x.data_ptr(), 64, x.data_ptr(), x.data_ptr(), 64, 0, 0,
                8, 64, 64, H.EPI_BIAS, stream())                                                  # misaligned A
+
+
+# -------------------------------------------------- bf16 activation storage (BASELINE.json configs[2])
+# Arithmetic is the fp32 kernels' (fp32 accumulate / statistics / softmax); only the HBM element type of the
+# projection-side activations changes.  So each kernel must reproduce, to fp32 rounding, the fp32 result computed
+# from the SAME bf16-representable inputs, up to one final round-to-nearest-even of a bf16 output (2^-8 relative).
+BF = torch.bfloat16
+BF_OUT = dict(rtol=2.0 ** -7, atol=1e-6)            # one bf16 rounding of the output (+ fp32 noise around a tie)
+
+
+def _bf(t):
+    return t.to(BF).float()                          # bf16-representable fp32 values
+
+
+@pytest.mark.parametrize("rows,d", [(7, 64), (1000, 256), (65, 512)])
+def test_layernorm_bf16_storage(H, dev, rows, d):
+    torch.manual_seed(11)
+    x = (torch.randn(rows, d) * 2 + 0.5).requires_grad_(True)
+    g = (torch.rand(d) + 0.5).requires_grad_(True)
+    b = torch.randn(d).requires_grad_(True)
+    y = F.layer_norm(x, (d,), g, b, 1e-5)
+    dy = _bf(torch.randn(rows, d))
+    y.backward(dy)
+    xd, gd, bd = x.detach().to(dev), g.detach().to(dev), b.detach().to(dev)
+    yd = torch.empty(rows, d, device=dev, dtype=BF)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    H.call("vlg_layernorm_fwd_bf16", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), yd.data_ptr(), mean.data_ptr(),
+           rstd.data_ptr(), rows, d, 1e-5, stream())
+    assert_close(yd.float(), y.detach(), what="ln fwd -> bf16", **BF_OUT)
+    ns = H.load().vlg_layernorm_bwd_slabs(rows)
+    slabs = torch.empty(ns * 2 * d, device=dev)
+    res = torch.randn(rows, d)
+    dres, dyd = res.to(dev), dy.to(dev).to(BF)
+    H.call("vlg_layernorm_bwd_bf16", dyd.data_ptr(), xd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
+           dres.data_ptr(), dres.data_ptr(), slabs.data_ptr(), 2 * d, rows, d, stream())
+    assert_close(dres, res + x.grad, rtol=1e-4, atol=2e-5, what="ln dx from bf16 dy")
+    gb = reduce_slabs(H, slabs, 2 * d, ns, 2 * d, dev)
+    assert_close(gb[:d], g.grad, rtol=1e-4, atol=1e-4, what="ln dgamma from bf16 dy")
+    assert_close(gb[d:], b.grad, rtol=1e-4, atol=1e-4, what="ln dbeta from bf16 dy")
+
+
+@pytest.mark.parametrize("T,d,n_seq", [(4, 64, 5), (8, 128, 3), (16, 256, 6), (32, 128, 3)])
+def test_attention_bf16_storage(H, dev, T, d, n_seq):
+    torch.manual_seed(12)
+    qkv = _bf(torch.randn(1, T, n_seq, 3 * d)).requires_grad_(True)
+    want = O.temporal_attention(qkv, d // 64)
+    do = _bf(torch.randn(1, T, n_seq, d))
+    want.backward(do)
+    to_int = lambda t: t[0].permute(1, 0, 2).contiguous().view(n_seq * T, -1)
+    qd = to_int(qkv.detach()).to(dev).to(BF)
+    o = torch.zeros(n_seq * T, d, device=dev, dtype=BF)
+    H.call("vlg_attention_fwd_bf16", qd.data_ptr(), o.data_ptr(), n_seq, T, d, stream())
+    assert_close(o.float(), to_int(want.detach()), what="attention fwd (bf16 storage)", **BF_OUT)
+    dod = to_int(do).to(dev).to(BF)
+    dq = torch.zeros(n_seq * T, 3 * d, device=dev, dtype=BF)
+    H.call("vlg_attention_bwd_bf16", qd.data_ptr(), dod.data_ptr(), dq.data_ptr(), n_seq, T, d, stream())
+    assert_close(dq.float(), to_int(qkv.grad), rtol=2.0 ** -7, atol=1e-5, what="attention bwd (bf16 storage)")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 768, 256), (333, 256, 1024)])
+def test_linear_bf16_storage(H, dev, M, N, K):
+    """Every (operand storage, epilogue) combination the bf16 step launches.  Weights are rounded to bf16 inside the
+    kernel (fragment read), so the fp64 reference uses bf16-rounded weights as well; outputs then differ from it by
+    fp32 accumulation noise and, for bf16 outputs, one final rounding."""
+    torch.manual_seed(13)
+    FL = H.EPI_BF16
+    a, w, bias = _bf(torch.randn(M, K)), _bf(torch.randn(N, K) / math.sqrt(K)), torch.randn(N)
+    ad, wd, bd = a.to(dev).to(BF), w.to(dev), bias.to(dev)
+    ref = (a.double() @ w.double().t() + bias.double())
+    # forward: bias -> bf16 (QKV), bias+gelu -> bf16 pair (FFN1), bias+resid -> fp32 (out-proj / FFN2)
+    c = torch.zeros(M, N, device=dev, dtype=BF)
+    H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, 0, M, N, K,
+           H.EPI_BIAS | FL | H.EPI_A_BF16 | H.EPI_OUT_BF16, stream())
+    assert_close(c.float(), ref.float(), what="fwd bias (bf16 in/out)", **BF_OUT)
+    u = torch.zeros(M, N, device=dev, dtype=BF)
+    H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, u.data_ptr(), M, N, K,
+           H.EPI_BIAS | H.EPI_GELU | FL | H.EPI_A_BF16 | H.EPI_OUT_BF16, stream())
+    assert_close(u.float(), ref.float(), what="fwd pre-activation (bf16)", **BF_OUT)
+    assert_close(c.float(), F.gelu(ref).float(), what="fwd gelu (bf16)", rtol=2.0 ** -7, atol=2e-6)
+    resid = torch.randn(M, N)
+    rd, c32 = resid.to(dev), torch.zeros(M, N, device=dev)
+    H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c32.data_ptr(), N, rd.data_ptr(), 0, M, N, K,
+           H.EPI_BIAS | H.EPI_RESID | FL | H.EPI_A_BF16, stream())
+    assert_close(c32, (ref + resid.double()).float(), rtol=1e-4, atol=1e-5, what="fwd bias+resid (bf16 A, fp32 out)")
+    # data gradient: dY fp32 or bf16 -> dX bf16; with gelu' of a bf16 pre-activation
+    dy = _bf(torch.randn(M, N))
+    dref = dy.double() @ w.double()
+    for dy_dev, bits, tag in ((dy.to(dev), 0, "fp32 dY"), (dy.to(dev).to(BF), H.EPI_A_BF16, "bf16 dY")):
+        dx = torch.zeros(M, K, device=dev, dtype=BF)
+        H.call("vlg_linear_dgrad", dy_dev.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, 0, M, N, K,
+               FL | bits | H.EPI_OUT_BF16, stream())
+        assert_close(dx.float(), dref.float(), what="dgrad -> bf16 (%s)" % tag, rtol=2.0 ** -7, atol=1e-5)
+    pre = _bf(torch.randn(M, K))
+    pd = pre.to(dev).to(BF)
+    dx = torch.zeros(M, K, device=dev, dtype=BF)
+    H.call("vlg_linear_dgrad", dy.to(dev).data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, pd.data_ptr(), M, N, K,
+           H.EPI_DGELU | FL | H.EPI_OUT_BF16, stream())
+    uu = pre.double().requires_grad_(True)
+    F.gelu(uu).backward(dref)
+    assert_close(dx.float(), uu.grad.float(), what="dgrad * gelu' (bf16 aux/out)", rtol=2.0 ** -7, atol=1e-5)
+    # weight gradient: (fp32 | bf16) dY with bf16 X -> fp32 slabs
+    x = _bf(torch.randn(M, K))
+    xd = x.to(dev).to(BF)
+    ns = H.load().vlg_linear_wgrad_slabs_for(M, N, K, H.EPI_BF16)
+    stride = N * K + N
+    sc = math.sqrt(M)
+    for dy_dev, bits, tag in ((dy.to(dev), 0, "fp32 dY"), (dy.to(dev).to(BF), H.EPI_A_BF16, "bf16 dY")):
+        slabs = torch.full((ns * stride,), float("nan"), device=dev)
+        H.call("vlg_linear_wgrad", dy_dev.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, M, N, K,
+               FL | bits | H.EPI_B_BF16, stream())
+        g = reduce_slabs(H, slabs, stride, ns, stride, dev)
+        assert_close(g[:N * K].view(N, K) / sc, (dy.double().t() @ x.double()).float() / sc, rtol=1e-4, atol=1e-5,
+                     what="wgrad (%s, bf16 X)" % tag)
+        assert_close(g[N * K:] / sc, dy.double().sum(0).float() / sc, rtol=1e-4, atol=1e-5, what="bias grad (%s)" % tag)
+    # storage flags without the bf16 MFMA flag, or a combination no step uses, are refused
+    with pytest.raises(H.HipError):
+        H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, 0, M, N, K,
+               H.EPI_BIAS | H.EPI_A_BF16, stream())

@@ -123,15 +123,17 @@ def test_full_size_properties(dev, shape):
     assert last < first, (first, last)
 
 
-def test_bf16_projection_mode(dev):
-    """BASELINE.json configs[2]: the same step with bf16 MFMA projections (operands rounded to bf16, fp32
-    accumulate, fp32 tensors).  bf16 has 8 significand bits, so this is NOT a 1e-4 parity mode: the loss must
-    agree with the fp32 oracle to 2e-2 relative and every gradient tensor to 5e-2 in relative L2 (stated
+@pytest.mark.parametrize("precision,T", [("bf16", 16), ("bf16_mfma", 16), ("bf16", 8)])
+def test_bf16_projection_mode(dev, precision, T):
+    """BASELINE.json configs[2]: the same step with bf16 MFMA projections (fp32 accumulate), either with the
+    projection-side activations stored as bf16 in HBM ("bf16") or with fp32 tensors and operands rounded at
+    fragment-read time ("bf16_mfma").  bf16 has 8 significand bits, so this is NOT a 1e-4 parity mode: the loss
+    must agree with the fp32 oracle to 2e-2 relative and every gradient tensor to 5e-2 in relative L2 (stated
     tolerance), and training must still make progress."""
     from vlg.engine import LayoutEngine
     from vlg.spec import LayoutConfig, param_shapes
-    cfg = LayoutConfig(B=2, T=16, N=16, d=256, n_layers=2)
-    eng = LayoutEngine(cfg, dev, precision="bf16")
+    cfg = LayoutConfig(B=2, T=T, N=16, d=256, n_layers=2)
+    eng = LayoutEngine(cfg, dev, precision=precision)
     p = O.init_params(param_shapes(cfg), seed=1024)
     batch = O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=7)
     parts, grads = O.loss_and_grads(p, batch, cfg.n_layers)

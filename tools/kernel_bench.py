@@ -60,7 +60,7 @@ def main():
     add("gemm dgrad ff1", fl(ff, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_ff), ff, P(w_ff1), d, P(y_d), d, 0, M, ff, d, EPI_NONE | FLAGS, S))
     add("gemm dgrad ff2 (dgelu)", fl(d, ff), "F", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(y_ff), ff, P(x_ff2), M, d, ff, EPI_DGELU | FLAGS, S))
     for nm, n, k, dy, xx in (("qkv", 3 * d, d, x_3d, x_d), ("proj", d, d, y_d, x_d), ("ff1", ff, d, x_ff, x_d), ("ff2", d, ff, x_d, x_ff)):
-        ns = lib.vlg_linear_wgrad_slabs(M, n, k)
+        ns = lib.vlg_linear_wgrad_slabs_for(M, n, k, FLAGS)
         add("gemm wgrad %-4s (%d slabs)" % (nm, ns), fl(n, k), "F", lambda n=n, k=k, dy=dy, xx=xx: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, M, n, k, FLAGS, S))
         add("reduce wgrad %-4s" % nm, 4.0 * (n * k + n) * (ns + 1), "B", lambda n=n, k=k, ns=ns: hip.call("vlg_reduce_slabs", P(slabs), n * k + n, ns, P(red_dst), n * k + n, S))
     add("attention fwd", 16.0 * M * d, "B", lambda: hip.call("vlg_attention_fwd", P(x_3d), P(y_d), B * N, T, d, S))

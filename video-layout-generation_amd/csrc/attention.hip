@@ -23,8 +23,8 @@ struct AttnGeom {
 };
 
 // stage a T x 64 tile whose rows are `ld` floats apart into LDS
-template <int T>
-__device__ __forceinline__ void stage_tile(float* S, const float* __restrict__ src, int64_t ld, int lane) {
+template <int T, typename EL>
+__device__ __forceinline__ void stage_tile(float* S, const EL* __restrict__ src, int64_t ld, int lane) {
 #pragma unroll
     for (int r = 0; r < (T * 16 + 63) / 64; ++r) {
         const int idx = r * 64 + lane;
@@ -71,8 +71,8 @@ __device__ __forceinline__ void softmax_rows(float (&s)[AttnGeom<T>::JPL]) {
     for (int jj = 0; jj < JPL; ++jj) s[jj] *= inv;
 }
 
-template <int T>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+template <int T, typename EL = float>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const EL* __restrict__ qkv, EL* __restrict__ o,
                                                       int d, int n_heads) {
     using G = AttnGeom<T>;
     __shared__ __attribute__((aligned(16))) float sm[3 * T * LDT + T * (T + 1)];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
     const int64_t seq = blockIdx.x / n_heads;
     const int hh = blockIdx.x - (int)(seq * n_heads);
     const int64_t ld = 3 * (int64_t)d;
-    const float* base = qkv + seq * T * ld + hh * HD;
+    const EL* base = qkv + seq * T * ld + hh * HD;
     stage_tile<T>(Qs, base, ld, lane);
     stage_tile<T>(Ks, base + d, ld, lane);
     stage_tile<T>(Vs, base + 2 * d, ld, lane);
@@ -108,15 +108,15 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
                 acc[c].x += p * v.x; acc[c].y += p * v.y; acc[c].z += p * v.z; acc[c].w += p * v.w;
             }
         }
-        float* dst = o + (seq * T + i) * (int64_t)d + hh * HD + jg * G::CPL;
+        EL* dst = o + (seq * T + i) * (int64_t)d + hh * HD + jg * G::CPL;
 #pragma unroll
         for (int c = 0; c < G::CPL / 4; ++c) st4(dst + c * 4, acc[c]);
     }
 }
 
-template <int T>
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                      float* __restrict__ dqkv, int d, int n_heads) {
+template <int T, typename EL = float>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const EL* __restrict__ qkv, const EL* __restrict__ dout,
+                                                      EL* __restrict__ dqkv, int d, int n_heads) {
     using G = AttnGeom<T>;
     __shared__ __attribute__((aligned(16))) float sm[4 * T * LDT + 2 * T * (T + 1)];
     float* Qs = sm; float* Ks = sm + T * LDT; float* Vs = sm + 2 * T * LDT; float* Os = sm + 3 * T * LDT;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
     const int64_t seq = blockIdx.x / n_heads;
     const int hh = blockIdx.x - (int)(seq * n_heads);
     const int64_t ld = 3 * (int64_t)d;
-    const float* base = qkv + seq * T * ld + hh * HD;
+    const EL* base = qkv + seq * T * ld + hh * HD;
     stage_tile<T>(Qs, base, ld, lane);
     stage_tile<T>(Ks, base + d, ld, lane);
     stage_tile<T>(Vs, base + 2 * d, ld, lane);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
                 av[c].x += pp * g.x; av[c].y += pp * g.y; av[c].z += pp * g.z; av[c].w += pp * g.w;
             }
         }
-        float* dst = dqkv + (seq * T + r) * ld + hh * HD + c0;
+        EL* dst = dqkv + (seq * T + r) * ld + hh * HD + c0;
 #pragma unroll
         for (int c = 0; c < G::CPL / 4; ++c) {
             st4(dst + c * 4, aq[c]);
@@ -211,11 +211,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ void load_rows16(float4 (&x)[4], const float* __restrict__ base, int64_t ld, int r, int g) {
+template <typename EL>
+__device__ __forceinline__ void load_rows16(float4 (&x)[4], const EL* __restrict__ base, int64_t ld, int r, int g) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) x[f] = ld4(base + r * ld + 16 * f + 4 * g);
 }
-__device__ __forceinline__ void load_kmajor16(float4 (&x)[4], const float* __restrict__ base, int64_t ld, int c, int g) {
+template <typename EL>
+__device__ __forceinline__ void load_kmajor16(float4 (&x)[4], const EL* __restrict__ base, int64_t ld, int c, int g) {
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho) x[rho] = ld4(base + (4 * g + rho) * ld + 4 * c);
 }
@@ -242,7 +244,8 @@ __device__ __forceinline__ void contract_frames16(f32x4 (&out)[4], const float4 
     }
 }
 // lane (col, g) stores its 16 consecutive channels 16g .. 16g+15 of row `col`
-__device__ __forceinline__ void store_tiles16(float* __restrict__ dst, const f32x4 (&o)[4]) {
+template <typename EL>
+__device__ __forceinline__ void store_tiles16(EL* __restrict__ dst, const f32x4 (&o)[4]) {
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho) st4(dst + 4 * rho, make_float4(o[0][rho], o[1][rho], o[2][rho], o[3][rho]));
 }
@@ -273,8 +276,8 @@ __device__ __forceinline__ void softmax_p16(f32x4& s, int j, int g, float scale)
     }
 }
 
-__global__ __launch_bounds__(256) void attn16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                         int d, int n_heads, int64_t n_items) {
+template <typename EL>
+__device__ __forceinline__ void attn16_fwd_body(const EL* __restrict__ qkv, EL* __restrict__ o, int d, int n_heads, int64_t n_items) {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_items) return;                             // wave-uniform
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const float* __restrict
     const int hh = (int)(item - seq * n_heads);
     const int r = lane & 15, g = lane >> 4;
     const int64_t ld = 3 * (int64_t)d;
-    const float* base = qkv + seq * 16 * ld + hh * HD;
+    const EL* base = qkv + seq * 16 * ld + hh * HD;
     float4 qf[4], kf[4], vk[4];
     load_rows16(qf, base, ld, r, g);
     load_rows16(kf, base + d, ld, r, g);
@@ -295,9 +298,18 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const float* __restrict
     contract_frames16(acc, vk, pt);                           // O^T[c][i] = sum_j V[j][c] P^T[j][i]
     store_tiles16(o + (seq * 16 + r) * (int64_t)d + hh * HD + 16 * g, acc);
 }
+__global__ __launch_bounds__(256) void attn16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                         int d, int n_heads, int64_t n_items) {
+    attn16_fwd_body(qkv, o, d, n_heads, n_items);
+}
+__global__ __launch_bounds__(256) void attn16_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                              int d, int n_heads, int64_t n_items) {
+    attn16_fwd_body(qkv, o, d, n_heads, n_items);
+}
 
-__global__ __launch_bounds__(256) void attn16_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                         float* __restrict__ dqkv, int d, int n_heads, int64_t n_items) {
+template <typename EL>
+__device__ __forceinline__ void attn16_bwd_body(const EL* __restrict__ qkv, const EL* __restrict__ dout, EL* __restrict__ dqkv,
+                                                int d, int n_heads, int64_t n_items) {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_items) return;
@@ -305,8 +317,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const float* __restrict
     const int hh = (int)(item - seq * n_heads);
     const int r = lane & 15, g = lane >> 4;
     const int64_t ld = 3 * (int64_t)d;
-    const float* base = qkv + seq * 16 * ld + hh * HD;
-    const float* gbase = dout + seq * 16 * (int64_t)d + hh * HD;
+    const EL* base = qkv + seq * 16 * ld + hh * HD;
+    const EL* gbase = dout + seq * 16 * (int64_t)d + hh * HD;
     const float scale = 0.125f;
     f32x4 p, pt, ds, dst_;                                     // plain / transposed probabilities and dS
     {
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const float* __restrict
             ds[k] = p[k] * (dp[k] - dk) * scale;               // dS[i][j]
         }
     }
-    float* obase = dqkv + (seq * 16 + r) * ld + hh * HD + 16 * g;
+    EL* obase = dqkv + (seq * 16 + r) * ld + hh * HD + 16 * g;
     f32x4 acc[4];
     float4 xk[4];
     // dV[j][c] = sum_i P[i][j] dO[i][c]
@@ -356,17 +368,63 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const float* __restrict
     contract_frames16(acc, xk, dst_);
     store_tiles16(obase, acc);
 }
+__global__ __launch_bounds__(256) void attn16_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                         float* __restrict__ dqkv, int d, int n_heads, int64_t n_items) {
+    attn16_bwd_body(qkv, dout, dqkv, d, n_heads, n_items);
+}
+__global__ __launch_bounds__(256) void attn16_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                              bf16_t* __restrict__ dqkv, int d, int n_heads, int64_t n_items) {
+    attn16_bwd_body(qkv, dout, dqkv, d, n_heads, n_items);
+}
 
 static int attn_check(const void* a, const void* b, int64_t n_seq, int T, int d) {
     if (n_seq < 1 || d < HD || (d % HD) != 0) return VLG_ERR_SHAPE;
     if (T != 4 && T != 8 && T != 16 && T != 32) return VLG_ERR_SHAPE;
     if (n_seq * (d / HD) > 0x7fffffff) return VLG_ERR_SHAPE;
-    if (!vlg_aligned16(a) || !vlg_aligned16(b)) return VLG_ERR_ALIGN;
+    if (!vlg_aligned8(a) || !vlg_aligned8(b)) return VLG_ERR_ALIGN;
     return 0;
+}
+
+extern "C" int vlg_attention_fwd_bf16(const vlg_bf16* qkv_, vlg_bf16* o_, int64_t n_seq, int T, int d, void* stream) {
+    if (int e = attn_check(qkv_, o_, n_seq, T, d)) return e;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);
+    bf16_t* o = reinterpret_cast<bf16_t*>(o_);
+    const int H = d / HD;
+    const dim3 grid((unsigned)(n_seq * H)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    switch (T) {
+        case 4:  hipLaunchKernelGGL((attn_fwd_kernel<4, bf16_t>),  grid, block, 0, s, qkv, o, d, H); break;
+        case 8:  hipLaunchKernelGGL((attn_fwd_kernel<8, bf16_t>),  grid, block, 0, s, qkv, o, d, H); break;
+        case 16: hipLaunchKernelGGL(attn16_fwd_bf16_kernel, dim3((unsigned)((n_seq * H + 3) / 4)), dim3(256), 0, s, qkv, o, d,
+                                    H, n_seq * H); break;
+        default: hipLaunchKernelGGL((attn_fwd_kernel<32, bf16_t>), grid, block, 0, s, qkv, o, d, H); break;
+    }
+    return vlg_last_error();
+}
+
+extern "C" int vlg_attention_bwd_bf16(const vlg_bf16* qkv_, const vlg_bf16* dout_, vlg_bf16* dqkv_, int64_t n_seq, int T, int d,
+                                      void* stream) {
+    if (int e = attn_check(qkv_, dqkv_, n_seq, T, d)) return e;
+    if (!vlg_aligned8(dout_)) return VLG_ERR_ALIGN;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);
+    const bf16_t* dout = reinterpret_cast<const bf16_t*>(dout_);
+    bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_);
+    const int H = d / HD;
+    const dim3 grid((unsigned)(n_seq * H)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    switch (T) {
+        case 4:  hipLaunchKernelGGL((attn_bwd_kernel<4, bf16_t>),  grid, block, 0, s, qkv, dout, dqkv, d, H); break;
+        case 8:  hipLaunchKernelGGL((attn_bwd_kernel<8, bf16_t>),  grid, block, 0, s, qkv, dout, dqkv, d, H); break;
+        case 16: hipLaunchKernelGGL(attn16_bwd_bf16_kernel, dim3((unsigned)((n_seq * H + 3) / 4)), dim3(256), 0, s, qkv, dout,
+                                    dqkv, d, H, n_seq * H); break;
+        default: hipLaunchKernelGGL((attn_bwd_kernel<32, bf16_t>), grid, block, 0, s, qkv, dout, dqkv, d, H); break;
+    }
+    return vlg_last_error();
 }
 
 extern "C" int vlg_attention_fwd(const float* qkv, float* o, int64_t n_seq, int T, int d, void* stream) {
     if (int e = attn_check(qkv, o, n_seq, T, d)) return e;
+    if (!vlg_aligned16(qkv) || !vlg_aligned16(o)) return VLG_ERR_ALIGN;
     const int H = d / HD;
     const dim3 grid((unsigned)(n_seq * H)), block(64);
     hipStream_t s = (hipStream_t)stream;
@@ -383,7 +441,7 @@ extern "C" int vlg_attention_fwd(const float* qkv, float* o, int64_t n_seq, int 
 extern "C" int vlg_attention_bwd(const float* qkv, const float* dout, float* dqkv, int64_t n_seq, int T, int d,
                                  void* stream) {
     if (int e = attn_check(qkv, dqkv, n_seq, T, d)) return e;
-    if (!vlg_aligned16(dout)) return VLG_ERR_ALIGN;
+    if (!vlg_aligned16(dout) || !vlg_aligned16(qkv) || !vlg_aligned16(dqkv)) return VLG_ERR_ALIGN;
     const int H = d / HD;
     const dim3 grid((unsigned)(n_seq * H)), block(64);
     hipStream_t s = (hipStream_t)stream;

@@ -27,20 +27,14 @@
 
 #include "gemm_tile.h"
 
-struct GemmArgs {
-    const float* A; const float* B; float* C;
-    const float* bias; const float* aux_in; float* aux_out;
-    int64_t M;               // rows of C (non-contraction extent of A)
-    int N;                   // cols of C (non-contraction extent of B)
-    int64_t Kc;              // contraction extent
-    int lda, ldb, ldc;
-    int tiles_m, tiles_n, splits;
-    int64_t kc_per_split, slab_stride, colsum_off;
-    unsigned long long* clock_probe;   // diagnostic only (VLG_GEMM_CLOCK_PROBE): {shader ticks, 100 MHz ticks} per block
-};
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool BF16>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
+    using EO = float;
+    const float* const gA = static_cast<const float*>(g.A);
+    const float* const gB = static_cast<const float*>(g.B);
+    const float* const gAuxIn = static_cast<const float*>(g.aux_in);
+    float* const gAuxOut = static_cast<float*>(g.aux_out);
     constexpr int WM = (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 4 : 1);
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -94,22 +88,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     float4 ra[TA::NV], rb[TB::NV];
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
     auto chunk = [&](const float* as, const float* bs, int s) {
-        if constexpr (BF16) {
-            // mixed precision: operands rounded to bf16 at fragment-read time, fp32 accumulate.  One call covers
-            // 8 k-values like the fp32 path, so two calls make one 16-deep MFMA: do the work on even s only.
-            if (s & 1) return;
-            bf16x8 a16[TM], b16[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a16[i] = TA::frag16(as, (wm * TM + i) * 32 + l31, s >> 1, h);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b16[j] = TB::frag16(bs, (wn * TN + j) * 32 + l31, s >> 1, h);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a16[i], b16[j], acc[i][j], 0, 0, 0);
-            return;
-        }
         float a[TM][4], b[TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i) TA::frag(a[i], as, (wm * TM + i) * 32 + l31, s, h);
@@ -127,13 +105,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     // other LDS buffer and the registers are refilled with tile kt+DEPTH (DEPTH tiles travel global -> register at once).
     auto mainloop = [&](auto guard_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;
-        constexpr int DEPTH = BF16 ? 2 : 1;      // bf16 MFMAs are 16x faster: the loop is load-latency bound, so keep
-                                                 // two tiles in flight per block (128 KB per CU) instead of one
-        float4 ra1[TA::NV], rb1[TB::NV];         // second register stage (DEPTH == 2 only)
+        constexpr int DEPTH = 1;                 // tiles travelling global -> register at once
         auto load = [&](float4 (&xa)[TA::NV], float4 (&xb)[TB::NV], int t) {
             const int64_t k0 = kbeg + (int64_t)t * BK;
-            TA::template gload<GUARD>(xa, g.A, g.lda, m0, g.M, k0, kend, tid);
-            TB::template gload<GUARD>(xb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+            TA::template gload<GUARD>(xa, gA, g.lda, m0, g.M, k0, kend, tid);
+            TB::template gload<GUARD>(xb, gB, g.ldb, n0, g.N, k0, kend, tid);
         };
         auto iter = [&](int kt, float4 (&xa)[TA::NV], float4 (&xb)[TB::NV]) {
             const int cur = kt & 1;
@@ -163,18 +139,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
             TB::sstore(rb, Bs0, tid);
         }
         if (nk > 1) load(ra, rb, 1);
-        if constexpr (DEPTH == 2) {
-            if (nk > 2) load(ra1, rb1, 2);
-        }
         __syncthreads();
-        if constexpr (DEPTH == 1) {
-            for (int kt = 0; kt < nk; ++kt) iter(kt, ra, rb);
-        } else {
-            for (int kt = 0; kt < nk; kt += 2) {          // tile kt+1 is in (ra, rb) on even, in (ra1, rb1) on odd iterations
-                iter(kt, ra, rb);
-                if (kt + 1 < nk) iter(kt + 1, ra1, rb1);
-            }
-        }
+        for (int kt = 0; kt < nk; ++kt) iter(kt, ra, rb);
     };
     // interior blocks (every tile fully inside both operands) take the unguarded instantiation
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) % BK) == 0);
@@ -187,7 +153,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     }
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h.
     // 32 lanes of a half write one 128-B row segment per store.
-    float* Cs = g.C + (int64_t)split * g.slab_stride;
+    EO* Cs = static_cast<EO*>(g.C) + (int64_t)split * g.slab_stride;
     const int64_t row0 = m0 + wm * TM * 32 + 4 * h;
     const int col0 = n0 + wn * TN * 32 + l31;
     const int64_t base = row0 * g.ldc + col0;
@@ -204,7 +170,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
-                        aux[r] = (!GUARD || row0 + ro < g.M) ? g.aux_in[base + ro * g.ldc + j * 32] : 0.f;
+                        aux[r] = (!GUARD || row0 + ro < g.M) ? ld1(gAuxIn + base + ro * g.ldc + j * 32) : 0.f;
                     }
                 }
 #pragma unroll
@@ -213,17 +179,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
                     if (GUARD && row0 + ro >= g.M) continue;
                     const int64_t o = base + ro * g.ldc + j * 32;
                     float v = acc[i][j][r] + bv[j];
-                    if constexpr ((EPI & VLG_EPI_GELU) != 0) { g.aux_out[o] = v; v = gelu_f(v); }
+                    if constexpr ((EPI & VLG_EPI_GELU) != 0) { st1(gAuxOut + o, v); v = gelu_f(v); }
                     if constexpr ((EPI & VLG_EPI_RESID) != 0) v += aux[r];
                     if constexpr ((EPI & VLG_EPI_DGELU) != 0) v *= dgelu_f(aux[r]);
-                    Cs[o] = v;
+                    st1(Cs + o, v);
                 }
             }
     };
     if (full) emit(std::false_type{});
     else emit(std::true_type{});
     if constexpr (COLSUM) {
-        if (tn == 0 && tid < BM && m0 + tid < g.M) Cs[g.colsum_off + m0 + tid] = colacc;
+        if (tn == 0 && tid < BM && m0 + tid < g.M) st1(Cs + g.colsum_off + m0 + tid, colacc);
     }
 }
 
@@ -246,33 +212,39 @@ static int gemm_bk_override() {
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
-static int launch_gemm(GemmArgs g, hipStream_t s, bool bf16 = false) {
+static int launch_gemm(GemmArgs g, hipStream_t s) {
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (g.N + BN - 1) / BN;
     const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.splits;
     if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
     const dim3 grid((unsigned)blocks), block(GEMM_THREADS);
     g.clock_probe = vlg_gemm_clock_probe;
-    if (bf16) {   // bf16 MFMA: the loop is staging-bound, so the deeper tile (fewer barriers per byte) is used
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM, true>), grid, block, 0, s, g);
-        return vlg_last_error();
-    }
     if constexpr (BM == 128 && BN == 128) {
         const int forced = gemm_bk_override();
         const bool heavy_epilogue = (EPI & (VLG_EPI_GELU | VLG_EPI_DGELU)) != 0;
         if (forced == 16 || (forced != 32 && heavy_epilogue)) {
-            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, A_KC, B_KC, EPI, COLSUM, false>), grid, block, 0, s, g);
+            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, A_KC, B_KC, EPI, COLSUM>), grid, block, 0, s, g);
             return vlg_last_error();
         }
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM, false>), grid, block, 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM>), grid, block, 0, s, g);
     return vlg_last_error();
 }
 
+// bf16-MFMA kernels with bf16 LDS tiles (gemm_bf16.hip)
+int vlg_gemm16_fwd(GemmArgs g, int epilogue, int io, hipStream_t s);
+int vlg_gemm16_dgrad(GemmArgs g, int epilogue, int io, hipStream_t s);
+int vlg_gemm16_wgrad(GemmArgs g, int io, hipStream_t s);
+// storage bits of the epilogue / flags word -> IO template value (bit 0 A, bit 1 B, bit 2 C + aux)
+static int gemm_io_bits(int flags) {
+    return ((flags & VLG_EPI_A_BF16) ? 1 : 0) | ((flags & VLG_EPI_B_BF16) ? 2 : 0) | ((flags & VLG_EPI_OUT_BF16) ? 4 : 0);
+}
+#define VLG_EPI_STORAGE (VLG_EPI_A_BF16 | VLG_EPI_B_BF16 | VLG_EPI_OUT_BF16)
+
 static bool gemm_ptr_ok(const void* p, int ld) { return vlg_aligned16(p) && (ld & 3) == 0; }
 
-extern "C" int vlg_linear_fwd(const float* A, int lda, const float* W, int ldw, const float* bias,
-                              float* C, int ldc, const float* aux_in, float* aux_out,
+extern "C" int vlg_linear_fwd(const void* A, int lda, const float* W, int ldw, const float* bias,
+                              void* C, int ldc, const void* aux_in, void* aux_out,
                               int64_t M, int N, int K, int epilogue, void* stream) {
     if (M < 1 || N < 1 || K < 4 || (K & 3) || lda < K || ldw < K || ldc < N) return VLG_ERR_SHAPE;
     if (!gemm_ptr_ok(A, lda) || !gemm_ptr_ok(W, ldw) || !C) return VLG_ERR_ALIGN;
@@ -282,26 +254,30 @@ extern "C" int vlg_linear_fwd(const float* A, int lda, const float* W, int ldw, 
     g.splits = 1; g.kc_per_split = K; g.slab_stride = 0; g.colsum_off = 0;
     hipStream_t s = (hipStream_t)stream;
     const bool bf16 = (epilogue & VLG_EPI_BF16) != 0;
-    epilogue &= ~VLG_EPI_BF16;
+    const int io = gemm_io_bits(epilogue);
+    epilogue &= ~(VLG_EPI_BF16 | VLG_EPI_STORAGE);
     if ((epilogue & VLG_EPI_BIAS) && !bias) return VLG_ERR_SHAPE;
     if ((epilogue & (VLG_EPI_RESID | VLG_EPI_DGELU)) && !aux_in) return VLG_ERR_SHAPE;
     if ((epilogue & VLG_EPI_GELU) && !aux_out) return VLG_ERR_SHAPE;
     const bool narrow = N <= 32;
+    if (io != 0 && !bf16) return VLG_ERR_SHAPE;      // bf16 activation storage exists for the bf16 MFMA mode only
+    if ((io & 1) && (lda & 7)) return VLG_ERR_ALIGN;
+    if (bf16) return vlg_gemm16_fwd(g, epilogue, io, s);
     switch (epilogue) {
         case VLG_EPI_BIAS:
-            return narrow ? launch_gemm<128, 32, true, true, VLG_EPI_BIAS, false>(g, s, bf16)
-                          : launch_gemm<128, 128, true, true, VLG_EPI_BIAS, false>(g, s, bf16);
+            return narrow ? launch_gemm<128, 32, true, true, VLG_EPI_BIAS, false>(g, s)
+                          : launch_gemm<128, 128, true, true, VLG_EPI_BIAS, false>(g, s);
         case VLG_EPI_BIAS | VLG_EPI_GELU:
-            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false>(g, s, bf16);
+            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false>(g, s);
         case VLG_EPI_BIAS | VLG_EPI_RESID:
-            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false>(g, s, bf16);
+            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false>(g, s);
         default:
             return VLG_ERR_SHAPE;
     }
 }
 
-extern "C" int vlg_linear_dgrad(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx,
-                                const float* aux_in, int64_t M, int N, int K, int epilogue, void* stream) {
+extern "C" int vlg_linear_dgrad(const void* dY, int ldy, const float* W, int ldw, void* dX, int ldx,
+                                const void* aux_in, int64_t M, int N, int K, int epilogue, void* stream) {
     // dX[M,K] = dY[M,N] . W[N,K]  : contraction over N, W is contraction-major
     if (M < 1 || N < 4 || (N & 3) || K < 4 || (K & 3) || ldy < N || ldw < K || ldx < K) return VLG_ERR_SHAPE;
     if (!gemm_ptr_ok(dY, ldy) || !gemm_ptr_ok(W, ldw) || !dX) return VLG_ERR_ALIGN;
@@ -311,13 +287,18 @@ extern "C" int vlg_linear_dgrad(const float* dY, int ldy, const float* W, int ld
     g.splits = 1; g.kc_per_split = N;
     hipStream_t s = (hipStream_t)stream;
     const bool bf16 = (epilogue & VLG_EPI_BF16) != 0;
-    epilogue &= ~VLG_EPI_BF16;
+    const int io = gemm_io_bits(epilogue);
+    epilogue &= ~(VLG_EPI_BF16 | VLG_EPI_STORAGE);
+    if (io != 0 && !bf16) return VLG_ERR_SHAPE;
+    if ((io & 1) && (ldy & 7)) return VLG_ERR_ALIGN;
+    if (epilogue == VLG_EPI_DGELU && !aux_in) return VLG_ERR_SHAPE;
+    if (bf16) return vlg_gemm16_dgrad(g, epilogue, io, s);
     switch (epilogue) {
         case VLG_EPI_NONE:
-            return launch_gemm<128, 128, true, false, VLG_EPI_NONE, false>(g, s, bf16);
+            return launch_gemm<128, 128, true, false, VLG_EPI_NONE, false>(g, s);
         case VLG_EPI_DGELU:
             if (!aux_in) return VLG_ERR_SHAPE;
-            return launch_gemm<128, 128, true, false, VLG_EPI_DGELU, false>(g, s, bf16);
+            return launch_gemm<128, 128, true, false, VLG_EPI_DGELU, false>(g, s);
         default:
             return VLG_ERR_SHAPE;
     }
@@ -325,7 +306,7 @@ extern "C" int vlg_linear_dgrad(const float* dY, int ldy, const float* W, int ld
 
 // split plan for the weight gradient: enough blocks to fill 256 CUs x 2 blocks, each split a
 // multiple of BK token rows
-static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per) {
+static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per, bool bf16 = false) {
     const int bm = N <= 32 ? 32 : 128;
     const int64_t tiles = ((N + bm - 1) / bm) * (int64_t)((K + 127) / 128);
     int64_t want = 512 / tiles;                      // blocks <= 512 = 256 CUs x 2 resident blocks: one full wave, no tail
@@ -333,7 +314,8 @@ static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per) {
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;
     int64_t p = (M + want - 1) / want;
-    p = (p + 31) / 32 * 32;
+    const int kt = bf16 ? 64 : 32;                   // whole K tiles: 32 token rows (fp32 kernel), 64 (bf16 kernel)
+    p = (p + kt - 1) / kt * kt;
     *per = p;
     *splits = (int)((M + p - 1) / p);
 }
@@ -343,8 +325,13 @@ extern "C" int vlg_linear_wgrad_slabs(int64_t M, int N, int K) {
     wgrad_plan(M, N, K, &splits, &per);
     return splits;
 }
+extern "C" int vlg_linear_wgrad_slabs_for(int64_t M, int N, int K, int flags) {
+    int splits; int64_t per;
+    wgrad_plan(M, N, K, &splits, &per, (flags & VLG_EPI_BF16) != 0);
+    return splits;
+}
 
-extern "C" int vlg_linear_wgrad(const float* dY, int ldy, const float* X, int ldx, float* slabs,
+extern "C" int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, float* slabs,
                                 int64_t slab_stride, int64_t M, int N, int K, int flags, void* stream) {
     // slab[s][n*K + k] = sum_{m in split s} dY[m,n] X[m,k] ;  slab[s][N*K + n] = sum_m dY[m,n]
     if (M < 1 || N < 4 || (N & 3) || K < 4 || (K & 3) || ldy < N || ldx < K) return VLG_ERR_SHAPE;
@@ -353,10 +340,14 @@ extern "C" int vlg_linear_wgrad(const float* dY, int ldy, const float* X, int ld
     GemmArgs g{};
     g.A = dY; g.B = X; g.C = slabs;
     g.M = N; g.N = K; g.Kc = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
-    wgrad_plan(M, N, K, &g.splits, &g.kc_per_split);
+    wgrad_plan(M, N, K, &g.splits, &g.kc_per_split, (flags & VLG_EPI_BF16) != 0);
     g.slab_stride = slab_stride; g.colsum_off = (int64_t)N * K;
     hipStream_t s = (hipStream_t)stream;
     const bool bf16 = (flags & VLG_EPI_BF16) != 0;
-    return N <= 32 ? launch_gemm<32, 128, false, false, VLG_EPI_NONE, true>(g, s, bf16)
-                   : launch_gemm<128, 128, false, false, VLG_EPI_NONE, true>(g, s, bf16);
+    const int io = gemm_io_bits(flags);
+    if (io != 0 && !bf16) return VLG_ERR_SHAPE;
+    if (((io & 1) && (ldy & 7)) || ((io & 2) && (ldx & 7))) return VLG_ERR_ALIGN;
+    if (bf16) return vlg_gemm16_wgrad(g, io, s);
+    return N <= 32 ? launch_gemm<32, 128, false, false, VLG_EPI_NONE, true>(g, s)
+                   : launch_gemm<128, 128, false, false, VLG_EPI_NONE, true>(g, s);
 }

@@ -1,0 +1,364 @@
+// bf16-MFMA GEMMs of the bf16 mode (BASELINE.json configs[2]): v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+//
+// Same three products as gemm.hip (forward A.W^T, data gradient dY.W, weight gradient dY^T.X split over tokens),
+// same 128x128 block tile / 2x2 wave tiles / XCD-aware tile order / slab outputs, but the operand tiles live in LDS
+// as bf16, 64 contraction steps deep, whatever the HBM element type (bf16 activations are copied, fp32 operands -
+// weights, residual-stream gradients - are rounded once on their way to LDS):
+//   KC image  [row][k]   rows of 64 bf16 + 8 pad = 36 dwords: the per-lane 16-byte fragment reads (ds_read_b128,
+//                        lane = row, half-wave h picks k = 16s + 8h ..+7) hit 16 distinct 4-bank slots per 16 lanes
+//   MC image  [k][row]   the operand is contraction-major in memory (W for the data gradient, dY and X for the weight
+//                        gradient), so the tile is stored exactly as it arrives and read with gfx950's TRANSPOSING
+//                        LDS read ds_read_b64_tr_b16: each 16-lane group fetches a 4(k) x 16(row) block and every
+//                        lane receives the 4 k-values of ITS row - two reads make the 8-deep MFMA operand.  Row
+//                        stride = BR*2 + 64 bytes, so the four k-rows of a block start 64 B apart modulo the 256-B
+//                        bank window: conflict-free.
+// Both images give lane (row = l & 31, h = l >> 5) the k-values 16s + 8h + j, j = 0..7, so A and B agree on the
+// contraction order whatever their layouts.
+// Algorithmic work per launch: 2*M*N*K flop; bytes = element sizes x (M*K + N*K + M*N) (+ aux operands): with
+// bf16 activations the 128 x 128 x 64 tile needs 16 MFMAs (512 cycles) per 32 KB staged - the kernel is priced
+// against HBM, not MFMA.
+#include "common.h"
+#include <type_traits>
+#include "gemm_tile.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+#define BK16 64
+
+// pack 8 fp32 values (two float4) into 8 bf16 (round to nearest even)
+__device__ __forceinline__ uint4 pack_bf16x8(float4 a, float4 b) {
+    const bf16x8 t = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w, (bf16_t)b.x, (bf16_t)b.y, (bf16_t)b.z, (bf16_t)b.w};
+    return __builtin_bit_cast(uint4, t);
+}
+
+// Register stage of one operand tile: raw loads, converted only when written to LDS (so the loads stay in flight).
+template <typename E, int NV> struct Stage16;
+template <int NV> struct Stage16<bf16_t, NV> { uint4 v[NV]; };
+template <int NV> struct Stage16<float, NV> { float4 lo[NV], hi[NV]; };
+
+template <int BR, bool KC>
+struct Tile16 {
+    static constexpr int RS = KC ? BK16 + 8 : BR + 32;                   // row stride of the LDS image, elements
+    static constexpr int ELEMS = KC ? BR * RS : BK16 * RS;
+    static constexpr int SLOTS = BR * BK16 / 8;                          // 16-byte (8-element) slots per tile
+    static constexpr int NV = (SLOTS + GEMM_THREADS - 1) / GEMM_THREADS;
+    static constexpr int PER_ROW = KC ? BK16 / 8 : BR / 8;               // slots per memory row
+
+    template <bool GUARD, typename E>
+    __device__ static __forceinline__ void gload(Stage16<E, NV>& st, const E* __restrict__ P, int ld,
+                                                 int64_t r0, int64_t R, int64_t k0, int64_t kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + GEMM_THREADS * i;
+            const bool live = (SLOTS % GEMM_THREADS == 0) || idx < SLOTS;
+            const int major = idx / PER_ROW, minor = (idx % PER_ROW) << 3;
+            int64_t grow = KC ? r0 + major : k0 + major;
+            int64_t gcol = KC ? k0 + minor : r0 + minor;
+            bool ok = live;
+            if constexpr (GUARD) {
+                const int64_t rlim = KC ? R : kend, clim = KC ? kend : R;     // clim is a multiple of 8 (checked on the host)
+                ok = live && grow < rlim && gcol < clim;
+                grow = grow < rlim ? grow : rlim - 1;
+                gcol = gcol < clim ? gcol : clim - 8;
+            } else if (!live) { grow = KC ? r0 : k0; gcol = KC ? k0 : r0; }
+            const E* src = P + grow * ld + gcol;
+            if constexpr (std::is_same<E, float>::value) {
+                const float4 a = ld4(src), b = ld4(src + 4);
+                st.lo[i] = ok ? a : f4_zero();
+                st.hi[i] = ok ? b : f4_zero();
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4*>(src);
+                st.v[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
+    template <typename E>
+    __device__ static __forceinline__ void sstore(const Stage16<E, NV>& st, bf16_t* S, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + GEMM_THREADS * i;
+            if (SLOTS % GEMM_THREADS != 0 && idx >= SLOTS) continue;
+            uint4 v;
+            if constexpr (std::is_same<E, float>::value) v = pack_bf16x8(st.lo[i], st.hi[i]);
+            else v = st.v[i];
+            *reinterpret_cast<uint4*>(S + (idx / PER_ROW) * RS + ((idx % PER_ROW) << 3)) = v;
+        }
+    }
+    // MFMA operand of the 32-row sub-tile starting at tile row rb for k16-step s: lane (l31, h) gets k = 16s + 8h + 0..7
+    __device__ static __forceinline__ bf16x8 frag(const bf16_t* S, int rb, int s, int lane) {
+        if constexpr (KC) {
+            return *reinterpret_cast<const bf16x8*>(S + (rb + (lane & 31)) * RS + 16 * s + 8 * (lane >> 5));
+        } else {
+            // group g = lane>>4 covers rows rb + 16(g&1) .. +15 and k = 16s + 8(g>>1) .. +7; lane 4q+p of the group supplies
+            // the address of k-row q, rows 4p..4p+3 and receives the 4 k-values of row (lane & 15)
+            const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+            const bf16_t* a = S + (16 * s + 8 * (g >> 1) + q) * RS + rb + 16 * (g & 1) + 4 * p;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * RS));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, t);
+        }
+    }
+    // column sums of the tile this thread staged (weight gradient: bias gradient), 8 rows per thread
+    template <typename E>
+    __device__ static __forceinline__ void colsum_add(float (&acc)[8], const Stage16<E, NV>& st) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if constexpr (std::is_same<E, float>::value) {
+                acc[0] += st.lo[i].x; acc[1] += st.lo[i].y; acc[2] += st.lo[i].z; acc[3] += st.lo[i].w;
+                acc[4] += st.hi[i].x; acc[5] += st.hi[i].y; acc[6] += st.hi[i].z; acc[7] += st.hi[i].w;
+            } else {
+                const unsigned w[4] = {st.v[i].x, st.v[i].y, st.v[i].z, st.v[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * j] += __uint_as_float(w[j] << 16);
+                    acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+                }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, typename EA, typename EB, typename EO>
+__device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
+    static_assert(!COLSUM || !A_KC, "column sums are taken from a contraction-major A tile");
+    const EA* const gA = static_cast<const EA*>(g.A);
+    const EB* const gB = static_cast<const EB*>(g.B);
+    const EO* const gAuxIn = static_cast<const EO*>(g.aux_in);
+    EO* const gAuxOut = static_cast<EO*>(g.aux_out);
+    constexpr int WM = (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 4 : 1);
+    constexpr int WN = 4 / WM;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    using TA = Tile16<BM, A_KC>;
+    using TB = Tile16<BN, B_KC>;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (TA::ELEMS + TB::ELEMS)];
+    bf16_t* const As0 = smem;
+    bf16_t* const Bs0 = smem + 2 * TA::ELEMS;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int split = swz / ntile;
+    const int tile = swz - split * ntile;
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const int64_t kbeg = (int64_t)split * g.kc_per_split;
+    int64_t kend = kbeg + g.kc_per_split;
+    if (kend > g.Kc) kend = g.Kc;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) csum[j] = 0.f;
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        bv[j] = 0.f;
+        if constexpr ((EPI & VLG_EPI_BIAS) != 0) {
+            const int col = n0 + (wn * TN + j) * 32 + l31;
+            bv[j] = g.bias[col < g.N ? col : g.N - 1];
+        }
+    }
+
+    const int nk = (int)((kend - kbeg + BK16 - 1) / BK16);
+    auto kstep = [&](const bf16_t* as, const bf16_t* bs, int s) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = TA::frag(as, (wm * TM + i) * 32, s, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = TB::frag(bs, (wn * TN + j) * 32, s, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    auto mainloop = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+        Stage16<EA, TA::NV> sa0, sa1;
+        Stage16<EB, TB::NV> sb0, sb1;
+        auto load = [&](Stage16<EA, TA::NV>& xa, Stage16<EB, TB::NV>& xb, int t) {
+            const int64_t k0 = kbeg + (int64_t)t * BK16;
+            TA::template gload<GUARD>(xa, gA, g.lda, m0, g.M, k0, kend, tid);
+            TB::template gload<GUARD>(xb, gB, g.ldb, n0, g.N, k0, kend, tid);
+        };
+        // one iteration: the MFMAs of the tile in LDS buffer kt&1; in the middle, tile kt+1 (in registers) goes to the other
+        // buffer and its registers are refilled with tile kt+3 - two tiles are in flight between HBM and LDS at any time
+        auto iter = [&](int kt, Stage16<EA, TA::NV>& xa, Stage16<EB, TB::NV>& xb) {
+            const int cur = kt & 1;
+            const bf16_t* as = As0 + cur * TA::ELEMS;
+            const bf16_t* bs = Bs0 + cur * TB::ELEMS;
+            kstep(as, bs, 0);
+            kstep(as, bs, 1);
+            if (kt + 1 < nk) {
+                if constexpr (COLSUM) { if (tn == 0) TA::colsum_add(csum, xa); }
+                TA::sstore(xa, As0 + (cur ^ 1) * TA::ELEMS, tid);
+                TB::sstore(xb, Bs0 + (cur ^ 1) * TB::ELEMS, tid);
+            }
+            if (kt + 3 < nk) load(xa, xb, kt + 3);
+            kstep(as, bs, 2);
+            kstep(as, bs, 3);
+            __syncthreads();
+        };
+        if (nk > 0) {
+            load(sa0, sb0, 0);
+            if constexpr (COLSUM) { if (tn == 0) TA::colsum_add(csum, sa0); }
+            TA::sstore(sa0, As0, tid);
+            TB::sstore(sb0, Bs0, tid);
+        }
+        if (nk > 1) load(sa0, sb0, 1);
+        if (nk > 2) load(sa1, sb1, 2);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {            // tile kt+1 sits in (sa0, sb0) on even, in (sa1, sb1) on odd iterations
+            iter(kt, sa0, sb0);
+            if (kt + 1 < nk) iter(kt + 1, sa1, sb1);
+        }
+    };
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) % BK16) == 0);
+    if (interior) mainloop(std::false_type{});
+    else mainloop(std::true_type{});
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h)
+    EO* Cs = static_cast<EO*>(g.C) + (int64_t)split * g.slab_stride;
+    const int64_t row0 = m0 + wm * TM * 32 + 4 * h;
+    const int col0 = n0 + wn * TN * 32 + l31;
+    const int64_t base = row0 * g.ldc + col0;
+    const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    auto emit = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (GUARD && col0 + j * 32 >= g.N) continue;
+                float aux[16];
+                if constexpr ((EPI & (VLG_EPI_RESID | VLG_EPI_DGELU)) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                        aux[r] = (!GUARD || row0 + ro < g.M) ? ld1(gAuxIn + base + ro * g.ldc + j * 32) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (GUARD && row0 + ro >= g.M) continue;
+                    const int64_t o = base + ro * g.ldc + j * 32;
+                    float v = acc[i][j][r] + bv[j];
+                    if constexpr ((EPI & VLG_EPI_GELU) != 0) { st1(gAuxOut + o, v); v = gelu_f(v); }
+                    if constexpr ((EPI & VLG_EPI_RESID) != 0) v += aux[r];
+                    if constexpr ((EPI & VLG_EPI_DGELU) != 0) v *= dgelu_f(aux[r]);
+                    st1(Cs + o, v);
+                }
+            }
+    };
+    if (full) emit(std::false_type{});
+    else emit(std::true_type{});
+    if constexpr (COLSUM) {
+        // every thread summed the 8 rows 8*(tid % PER_ROW) .. +7 of the tiles it staged: combine the GEMM_THREADS / PER_ROW
+        // threads that share a row group through LDS (the tiles are dead: the main loop ended on a barrier)
+        if (tn == 0) {
+            float* red = reinterpret_cast<float*>(smem);
+            constexpr int PR = TA::PER_ROW, NT = GEMM_THREADS / PR;         // threads per row group
+            if ((TA::SLOTS % GEMM_THREADS == 0) || tid < TA::SLOTS) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[(tid / PR) * BM + 8 * (tid % PR) + j] = csum[j];
+            }
+            __syncthreads();
+            constexpr int NTL = (TA::SLOTS < GEMM_THREADS ? TA::SLOTS : GEMM_THREADS) / PR;
+            if (tid < BM && m0 + tid < g.M) {
+                float s = 0.f;
+#pragma unroll 4
+                for (int t = 0; t < NTL; ++t) s += red[t * BM + tid];
+                st1(Cs + g.colsum_off + m0 + tid, s);
+            }
+            (void)NT;
+        }
+    }
+}
+
+// IO bit 0: A is bf16, bit 1: B is bf16, bit 2: C and the epilogue's auxiliary operands are bf16 (else float)
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, int IO>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmArgs g) {
+    using EA = std::conditional_t<(IO & 1) != 0, bf16_t, float>;
+    using EB = std::conditional_t<(IO & 2) != 0, bf16_t, float>;
+    using EO = std::conditional_t<(IO & 4) != 0, bf16_t, float>;
+    gemm16_body<BM, BN, A_KC, B_KC, EPI, COLSUM, EA, EB, EO>(g);
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, int IO>
+static int launch16(GemmArgs g, hipStream_t s) {
+    g.tiles_m = (int)((g.M + BM - 1) / BM);
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+    if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
+    g.clock_probe = nullptr;
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, IO>), dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, s, g);
+    return vlg_last_error();
+}
+
+// Entry points for gemm.hip's C ABI functions.  `io` = storage bits (see gemm_bf16_kernel); shapes were validated by the
+// caller, this layer adds the 8-element granularity of the bf16 slots.
+int vlg_gemm16_fwd(GemmArgs g, int epilogue, int io, hipStream_t s) {
+    if ((g.Kc & 7) || (g.lda & 7 && (io & 1)) || (g.lda & 3) || (g.ldb & 3)) return VLG_ERR_SHAPE;
+    const bool narrow = g.N <= 32;
+#define FWD(EPI, IO) (narrow ? launch16<128, 32, true, true, EPI, false, IO>(g, s) : launch16<128, 128, true, true, EPI, false, IO>(g, s))
+    if (epilogue == VLG_EPI_BIAS) {
+        switch (io) { case 0: return FWD(VLG_EPI_BIAS, 0); case 1: return FWD(VLG_EPI_BIAS, 1); case 5: return FWD(VLG_EPI_BIAS, 5); default: return VLG_ERR_SHAPE; }
+    }
+    if (narrow) return VLG_ERR_SHAPE;
+    if (epilogue == (VLG_EPI_BIAS | VLG_EPI_GELU)) {
+        if (io == 0) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false, 0>(g, s);
+        if (io == 5) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false, 5>(g, s);
+        return VLG_ERR_SHAPE;
+    }
+    if (epilogue == (VLG_EPI_BIAS | VLG_EPI_RESID)) {
+        if (io == 0) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false, 0>(g, s);
+        if (io == 1) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false, 1>(g, s);
+        return VLG_ERR_SHAPE;
+    }
+#undef FWD
+    return VLG_ERR_SHAPE;
+}
+
+int vlg_gemm16_dgrad(GemmArgs g, int epilogue, int io, hipStream_t s) {
+    // contraction over N (g.Kc), W rows are K-contiguous: both extents in 8-element slots
+    if ((g.Kc & 7) || (g.N & 7)) return VLG_ERR_SHAPE;
+    if (epilogue == VLG_EPI_NONE) {
+        switch (io) {
+            case 0: return launch16<128, 128, true, false, VLG_EPI_NONE, false, 0>(g, s);
+            case 4: return launch16<128, 128, true, false, VLG_EPI_NONE, false, 4>(g, s);
+            case 5: return launch16<128, 128, true, false, VLG_EPI_NONE, false, 5>(g, s);
+            default: return VLG_ERR_SHAPE;
+        }
+    }
+    if (epilogue == VLG_EPI_DGELU) {
+        if (io == 0) return launch16<128, 128, true, false, VLG_EPI_DGELU, false, 0>(g, s);
+        if (io == 4) return launch16<128, 128, true, false, VLG_EPI_DGELU, false, 4>(g, s);
+        return VLG_ERR_SHAPE;
+    }
+    return VLG_ERR_SHAPE;
+}
+
+int vlg_gemm16_wgrad(GemmArgs g, int io, hipStream_t s) {
+    // A = dY [tokens][N] and B = X [tokens][K] are both contraction-major: row extents in 8-element slots
+    if ((g.M & 7) || (g.N & 7)) return VLG_ERR_SHAPE;
+    const bool narrow = g.M <= 32;
+#define WG(IO) (narrow ? launch16<32, 128, false, false, VLG_EPI_NONE, true, IO>(g, s) : launch16<128, 128, false, false, VLG_EPI_NONE, true, IO>(g, s))
+    switch (io) { case 0: return WG(0); case 2: return WG(2); case 3: return WG(3); default: return VLG_ERR_SHAPE; }
+#undef WG
+}

@@ -8,6 +8,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define GEMM_THREADS 256
 
+struct GemmArgs {
+    const void* A; const void* B; void* C;       // element types are template parameters of the kernel (float or bf16_t)
+    const float* bias; const void* aux_in; void* aux_out;
+    int64_t M;               // rows of C (non-contraction extent of A)
+    int N;                   // cols of C (non-contraction extent of B)
+    int64_t Kc;              // contraction extent
+    int lda, ldb, ldc;
+    int tiles_m, tiles_n, splits;
+    int64_t kc_per_split, slab_stride, colsum_off;
+    unsigned long long* clock_probe;   // diagnostic only (VLG_GEMM_CLOCK_PROBE): {shader ticks, 100 MHz ticks} per block
+};
+
+
 // One operand tile: BR rows (non-contraction) x BK contraction steps.
 template <int BR, bool KC, int BK>
 struct Tile {
@@ -20,8 +33,9 @@ struct Tile {
     // GUARD = false: interior tile, plain loads that stay in flight until the LDS write.
     // GUARD = true : edge tile; address clamped into the operand and the value zeroed by a select
     //                (no branches).  Requires R >= 4 and kend - k0 >= 4 when anything is in range.
-    template <bool GUARD>
-    __device__ static __forceinline__ void gload(float4 (&r)[NV], const float* __restrict__ P, int ld,
+    // E = element type in memory (float, or bf16_t widened on load: the LDS tile is fp32 either way)
+    template <bool GUARD, typename E>
+    __device__ static __forceinline__ void gload(float4 (&r)[NV], const E* __restrict__ P, int ld,
                                                  int64_t r0, int64_t R, int64_t k0, int64_t kend, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -49,22 +63,6 @@ struct Tile {
             if constexpr (KC) st4(S + (idx / PER_ROW) * LDK + ((idx % PER_ROW) << 2), r[i]);
             else st4(S + (idx << 2), r[i]);
         }
-    }
-    // bf16 MFMA (32x32x16) fragment: the 8 k-values k = 16s + 8h + j of tile row `row`, rounded to bf16 (RNE)
-    // on the way from the fp32 LDS tile to the MFMA - HBM, staging and LDS layouts stay the fp32 ones
-    __device__ static __forceinline__ bf16x8 frag16(const float* S, int row, int s, int h) {
-        float f[8];
-        if constexpr (KC) {
-            const float4 t0 = ld4(S + row * LDK + 16 * s + 8 * h), t1 = ld4(S + row * LDK + 16 * s + 8 * h + 4);
-            f[0] = t0.x; f[1] = t0.y; f[2] = t0.z; f[3] = t0.w; f[4] = t1.x; f[5] = t1.y; f[6] = t1.z; f[7] = t1.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = S[(16 * s + 8 * h + j) * BR + row];
-        }
-        bf16x8 r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (__bf16)f[j];
-        return r;
     }
     // 4 fragment values of tile row `row` for chunk s, lane half h:  k = 8s + 4h + j
     __device__ static __forceinline__ void frag(float (&f)[4], const float* S, int row, int s, int h) {

@@ -16,7 +16,8 @@
 // E = floats per lane; V4 => lane holds E/4 float4 at columns 4*lane + 256*i, else scalars at lane + 64*i
 template <int E, bool V4>
 struct RowIO {
-    __device__ static __forceinline__ void load(const float* __restrict__ row, int lane, float (&v)[E]) {
+    template <typename EL>
+    __device__ static __forceinline__ void load(const EL* __restrict__ row, int lane, float (&v)[E]) {
         if constexpr (V4) {
 #pragma unroll
             for (int i = 0; i < E / 4; ++i) {
@@ -25,17 +26,18 @@ struct RowIO {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < E; ++i) v[i] = row[lane + 64 * i];
+            for (int i = 0; i < E; ++i) v[i] = ld1(row + lane + 64 * i);
         }
     }
-    __device__ static __forceinline__ void store(float* __restrict__ row, int lane, const float (&v)[E]) {
+    template <typename EL>
+    __device__ static __forceinline__ void store(EL* __restrict__ row, int lane, const float (&v)[E]) {
         if constexpr (V4) {
 #pragma unroll
             for (int i = 0; i < E / 4; ++i)
                 st4(row + 4 * lane + 256 * i, make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]));
         } else {
 #pragma unroll
-            for (int i = 0; i < E; ++i) row[lane + 64 * i] = v[i];
+            for (int i = 0; i < E; ++i) st1(row + lane + 64 * i, v[i]);
         }
     }
     // column index of register j
@@ -45,10 +47,10 @@ struct RowIO {
     }
 };
 
-template <int E, bool V4>
+template <int E, bool V4, typename EY = float>
 __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, float eps) {
+    EY* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, float eps) {
     constexpr int d = E * 64;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
@@ -74,9 +76,9 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(
     }
 }
 
-template <int E, bool V4>
+template <int E, bool V4, typename EY = float>
 __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+    const EY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ dres,
     float* __restrict__ dx_out, float* __restrict__ slabs, int64_t slab_stride, int64_t rows) {
     constexpr int d = E * 64;
@@ -177,6 +179,34 @@ extern "C" int vlg_layernorm_bwd(const float* dy, const float* x, const float* m
     const dim3 grid(ln_bwd_blocks(rows)), block(LN_BLOCK);
     hipStream_t s = (hipStream_t)stream;
 #define CALL(E, V4) hipLaunchKernelGGL((ln_bwd_kernel<E, V4>), grid, block, 0, s, dy, x, mean, rstd, gamma, dres, dx_out, slabs, slab_stride, rows);
+    LN_DISPATCH(d, CALL)
+#undef CALL
+    return vlg_last_error();
+}
+
+extern "C" int vlg_layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, vlg_bf16* y,
+                                      float* mean, float* rstd, int64_t rows, int d, float eps, void* stream) {
+    if (rows < 1) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(x) || !vlg_aligned8(y) || !vlg_aligned16(gamma) || !vlg_aligned16(beta)) return VLG_ERR_ALIGN;
+    const dim3 grid(ln_fwd_blocks(rows)), block(LN_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    bf16_t* yb = reinterpret_cast<bf16_t*>(y);
+#define CALL(E, V4) hipLaunchKernelGGL((ln_fwd_kernel<E, V4, bf16_t>), grid, block, 0, s, x, gamma, beta, yb, mean, rstd, rows, eps);
+    LN_DISPATCH(d, CALL)
+#undef CALL
+    return vlg_last_error();
+}
+
+extern "C" int vlg_layernorm_bwd_bf16(const vlg_bf16* dy, const float* x, const float* mean, const float* rstd,
+                                      const float* gamma, const float* dres, float* dx_out, float* slabs,
+                                      int64_t slab_stride, int64_t rows, int d, void* stream) {
+    if (rows < 1 || slab_stride < 2 * (int64_t)d) return VLG_ERR_SHAPE;
+    if (!vlg_aligned8(dy) || !vlg_aligned16(x) || !vlg_aligned16(gamma) || !vlg_aligned16(dx_out) ||
+        (dres && !vlg_aligned16(dres))) return VLG_ERR_ALIGN;
+    const dim3 grid(ln_bwd_blocks(rows)), block(LN_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    const bf16_t* dyb = reinterpret_cast<const bf16_t*>(dy);
+#define CALL(E, V4) hipLaunchKernelGGL((ln_bwd_kernel<E, V4, bf16_t>), grid, block, 0, s, dyb, x, mean, rstd, gamma, dres, dx_out, slabs, slab_stride, rows);
     LN_DISPATCH(d, CALL)
 #undef CALL
     return vlg_last_error();

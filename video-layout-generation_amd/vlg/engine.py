@@ -21,7 +21,8 @@ from typing import Dict, Optional
 import torch
 
 from . import hip
-from .hip import EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, call, ptr
+from .hip import (EPI_A_BF16, EPI_B_BF16, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_OUT_BF16, EPI_RESID, call,
+                  ptr)
 from .spec import (ADAM_BETA1, ADAM_BETA2, ADAM_EPS, ADAM_LR, BOX_DIM, IOU_EPS, LN_EPS, LOSS_W_CE,
                    LOSS_W_REG, LOSS_W_STRUCT, SMOOTH_L1_BETA, LayoutConfig, param_layout)
 
@@ -59,14 +60,21 @@ class LayoutEngine:
 
     def __init__(self, cfg: LayoutConfig, device: torch.device, seed: int = 1024,
                  lr: float = ADAM_LR, beta1: float = ADAM_BETA1, precision: str = "fp32"):
-        """precision: "fp32" = exact-fp32 MFMA projections (parity 1e-4); "bf16" = projection operands rounded
-        to bf16 for the 16x faster bf16 MFMA, fp32 accumulate, every tensor still fp32 in HBM (BASELINE.json
-        configs[2]); everything else (norms, attention, losses, Adam, master weights) is fp32 in both."""
+        """precision:
+        "fp32"      exact-fp32 MFMA projections, every tensor fp32 (parity 1e-4);
+        "bf16"      BASELINE.json configs[2]: bf16 MFMA projections (fp32 accumulate) AND the activations that only
+                    feed projections / attention (normalised inputs, q k v, attention output, FFN hidden and their
+                    gradients) stored as bf16 in HBM - the mode is HBM-bound, so the bytes are what count;
+        "bf16_mfma" bf16 MFMA projections with every tensor still fp32 in HBM (operands rounded at fragment-read time).
+        The residual stream and its gradient, layer-norm statistics, softmax, losses, weight gradients, Adam and the
+        master weights are fp32 in all three."""
         cfg.validate()
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be fp32 or bf16")
+        if precision not in ("fp32", "bf16", "bf16_mfma"):
+            raise ValueError("precision must be fp32, bf16 or bf16_mfma")
         self.precision = precision
-        self.gemm_flags = hip.EPI_BF16 if precision == "bf16" else 0
+        self.gemm_flags = 0 if precision == "fp32" else hip.EPI_BF16
+        self.bf16_store = precision == "bf16"
+        self._sfx = "_bf16" if self.bf16_store else ""
         hip.load()                                   # fail loudly before touching the GPU
         if device.type != "cuda":
             raise hip.HipError("LayoutEngine needs a HIP device (got %s); there is no CPU path" % device)
@@ -140,28 +148,29 @@ class LayoutEngine:
         M = self.capacity = tokens
         L = cfg.n_layers
         lib = hip.load()
+        act = dict(dtype=torch.bfloat16 if self.bf16_store else torch.float32, device=self.device)
         self.x = torch.empty(L + 1, M, d, **f32)          # residual stream entering each layer (+ final)
-        self.h1 = torch.empty(L, M, d, **f32)
-        self.qkv = torch.empty(L, M, 3 * d, **f32)
-        self.att = torch.empty(L, M, d, **f32)
+        self.h1 = torch.empty(L, M, d, **act)
+        self.qkv = torch.empty(L, M, 3 * d, **act)
+        self.att = torch.empty(L, M, d, **act)
         self.xmid = torch.empty(L, M, d, **f32)
-        self.h2 = torch.empty(L, M, d, **f32)
-        self.u = torch.empty(L, M, ff, **f32)             # FFN pre-activation
-        self.gl = torch.empty(L, M, ff, **f32)            # gelu(u)
+        self.h2 = torch.empty(L, M, d, **act)
+        self.u = torch.empty(L, M, ff, **act)             # FFN pre-activation
+        self.gl = torch.empty(L, M, ff, **act)            # gelu(u)
         self.stats = torch.empty(2 * L + 1, 2, M, **f32)  # mean / rstd of every layer-norm
-        self.xf = torch.empty(M, d, **f32)
+        self.xf = torch.empty(M, d, **act)
         self.out = torch.empty(M, cfg.n_out, **f32)
         self.dout = torch.empty(M, cfg.n_out, **f32)
-        self.dx = torch.empty(M, d, **f32)
-        self.dh = torch.empty(M, d, **f32)
-        self.du = torch.empty(M, ff, **f32)
-        self.dqkv = torch.empty(M, 3 * d, **f32)
+        self.dx = torch.empty(M, d, **f32)                # gradient of the residual stream
+        self.dh = torch.empty(M, d, **act)
+        self.du = torch.empty(M, ff, **act)
+        self.dqkv = torch.empty(M, 3 * d, **act)
         self.loss_scratch = torch.zeros(lib.vlg_layout_loss_scratch(), **f32)
         # one slab arena shared by every partial-sum producer (each is reduced before the next writes)
         emb_len = self.layout["l0.ln1_g"][0]
         need = [lib.vlg_embed_bwd_slabs() * emb_len, lib.vlg_layernorm_bwd_slabs(M) * 2 * d]
         for (n, k) in ((3 * d, d), (d, d), (ff, d), (d, ff), (cfg.n_out, d)):
-            need.append(lib.vlg_linear_wgrad_slabs(M, n, k) * (n * k + n))
+            need.append(lib.vlg_linear_wgrad_slabs_for(M, n, k, self.gemm_flags) * (n * k + n))
         self.slabs = torch.empty(max(need), **f32)
 
     # --------------------------------------------------------------------- helpers
@@ -178,30 +187,41 @@ class LayoutEngine:
             with self.timer.section(family, flops, nbytes):
                 call(name, *args)
 
+    @staticmethod
+    def _storage_bits(a=None, b=None, out=None) -> int:
+        """storage flags of a projection call from the dtypes of its activation operands"""
+        bf = torch.bfloat16
+        return ((EPI_A_BF16 if a is not None and a.dtype == bf else 0) | (EPI_B_BF16 if b is not None and b.dtype == bf else 0) |
+                (EPI_OUT_BF16 if out is not None and out.dtype == bf else 0))
+
     def _linear(self, a, w, b, c, M, N, K, epi, aux_in=None, aux_out=None):
-        nb = 4.0 * (M * K + N * K + M * N * (1 + (aux_in is not None) + (aux_out is not None)))
+        nb = (a.element_size() * M * K + 4.0 * N * K +
+              c.element_size() * M * N * (1 + (aux_in is not None) + (aux_out is not None)))
+        flags = epi | self.gemm_flags | self._storage_bits(a, None, c)
         self._timed("gemm_fwd" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_fwd", ptr(a), K, ptr(w), K,
-                    ptr(b), ptr(c), N, ptr(aux_in), ptr(aux_out), M, N, K, epi | self.gemm_flags, self._stream(), nbytes=nb)
+                    ptr(b), ptr(c), N, ptr(aux_in), ptr(aux_out), M, N, K, flags, self._stream(), nbytes=nb)
 
     def _dgrad(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux_in=None):
-        nb = 4.0 * (M * N + N * K + M * K * (1 + (aux_in is not None)))
+        nb = dy.element_size() * M * N + 4.0 * N * K + dx.element_size() * M * K * (1 + (aux_in is not None))
+        flags = epi | self.gemm_flags | self._storage_bits(dy, None, dx)
         self._timed("gemm_dgrad", 2.0 * M * N * K, "vlg_linear_dgrad", ptr(dy), N, ptr(w), K, ptr(dx), K,
-                    ptr(aux_in), M, N, K, epi | self.gemm_flags, self._stream(), nbytes=nb)
+                    ptr(aux_in), M, N, K, flags, self._stream(), nbytes=nb)
 
     def _wgrad(self, dy, x, wname, M, N, K):
         """grad[w | b] = (dy^T . x | colsum dy): split partials -> slab arena -> flat gradient."""
         lib = hip.load()
         stride = N * K + N
-        n_slabs = lib.vlg_linear_wgrad_slabs(M, N, K)
+        n_slabs = lib.vlg_linear_wgrad_slabs_for(M, N, K, self.gemm_flags)
         s = self._stream()
         self._timed("gemm_wgrad" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_wgrad", ptr(dy), N, ptr(x),
-                    K, ptr(self.slabs), stride, M, N, K, self.gemm_flags, s, nbytes=4.0 * (M * N + M * K + n_slabs * stride))
+                    K, ptr(self.slabs), stride, M, N, K, self.gemm_flags | self._storage_bits(dy, x), s,
+                    nbytes=dy.element_size() * M * N + x.element_size() * M * K + 4.0 * n_slabs * stride)
         off = self.layout[wname][0]
         call("vlg_reduce_slabs", ptr(self.slabs), stride, n_slabs, self.grads.data_ptr() + 4 * off, stride, s)
 
     def _ln_fwd(self, x, gname, y, stat, M):
         d = self.cfg.d
-        call("vlg_layernorm_fwd", ptr(x), ptr(self.p(gname)), ptr(self.p(gname[:-1] + "b")), ptr(y), ptr(stat[0]),
+        call("vlg_layernorm_fwd_bf16" if y.dtype == torch.bfloat16 else "vlg_layernorm_fwd", ptr(x), ptr(self.p(gname)), ptr(self.p(gname[:-1] + "b")), ptr(y), ptr(stat[0]),
              ptr(stat[1]), M, d, LN_EPS, self._stream())
 
     def _ln_bwd(self, dy, x, stat, gname, dres, dx_out, M):
@@ -209,7 +229,7 @@ class LayoutEngine:
         lib = hip.load()
         n_slabs = lib.vlg_layernorm_bwd_slabs(M)
         s = self._stream()
-        call("vlg_layernorm_bwd", ptr(dy), ptr(x), ptr(stat[0]), ptr(stat[1]), ptr(self.p(gname)), ptr(dres),
+        call("vlg_layernorm_bwd_bf16" if dy.dtype == torch.bfloat16 else "vlg_layernorm_bwd", ptr(dy), ptr(x), ptr(stat[0]), ptr(stat[1]), ptr(self.p(gname)), ptr(dres),
              ptr(dx_out), ptr(self.slabs), 2 * d, M, d, s)
         off = self.layout[gname][0]
         call("vlg_reduce_slabs", ptr(self.slabs), 2 * d, n_slabs, self.grads.data_ptr() + 4 * off, 2 * d, s)
@@ -245,7 +265,7 @@ class LayoutEngine:
             x = self.x[l]
             self._ln_fwd(x, pre + "ln1_g", self.h1[l], self.stats[2 * l], M)
             self._linear(self.h1[l], self.p(pre + "qkv_w"), self.p(pre + "qkv_b"), self.qkv[l], M, 3 * d, d, EPI_BIAS)
-            call("vlg_attention_fwd", ptr(self.qkv[l]), ptr(self.att[l]), B * N, T, d, s)
+            call("vlg_attention_fwd" + self._sfx, ptr(self.qkv[l]), ptr(self.att[l]), B * N, T, d, s)
             self._linear(self.att[l], self.p(pre + "proj_w"), self.p(pre + "proj_b"), self.xmid[l], M, d, d,
                          EPI_BIAS | EPI_RESID, aux_in=x)
             self._ln_fwd(self.xmid[l], pre + "ln2_g", self.h2[l], self.stats[2 * l + 1], M)
@@ -286,7 +306,7 @@ class LayoutEngine:
             # attention:  xmid = x + Wo attn(Wqkv h1 + b) + bo
             self._wgrad(self.dx, self.att[l], pre + "proj_w", M, d, d)
             self._dgrad(self.dx, self.p(pre + "proj_w"), self.dh, M, d, d)
-            call("vlg_attention_bwd", ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s)
+            call("vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s)
             self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d)
             self._dgrad(self.dqkv, self.p(pre + "qkv_w"), self.dh, M, 3 * d, d)
             self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)

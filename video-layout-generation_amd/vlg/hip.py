@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvlg_hip.so")
 
 EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_BF16 = 0, 1, 2, 4, 8, 16
+EPI_A_BF16, EPI_B_BF16, EPI_OUT_BF16 = 32, 64, 128      # bf16 activation storage (include/vlg_hip.h)
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 
@@ -26,14 +27,19 @@ SIGNATURES = {
     "vlg_embed_bwd_slabs": (I, []),
     "vlg_embed_bwd": (I, [P, P, P, P, L, I, I, I, I, I, P]),
     "vlg_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
+    "vlg_layernorm_fwd_bf16": (I, [P, P, P, P, P, P, L, I, F, P]),
     "vlg_layernorm_bwd_slabs": (I, [L]),
     "vlg_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, L, L, I, P]),
+    "vlg_layernorm_bwd_bf16": (I, [P, P, P, P, P, P, P, P, L, L, I, P]),
     "vlg_linear_fwd": (I, [P, I, P, I, P, P, I, P, P, L, I, I, I, P]),
     "vlg_linear_dgrad": (I, [P, I, P, I, P, I, P, L, I, I, I, P]),
     "vlg_linear_wgrad_slabs": (I, [L, I, I]),
+    "vlg_linear_wgrad_slabs_for": (I, [L, I, I, I]),
     "vlg_linear_wgrad": (I, [P, I, P, I, P, L, L, I, I, I, P]),
     "vlg_attention_fwd": (I, [P, P, L, I, I, P]),
     "vlg_attention_bwd": (I, [P, P, P, L, I, I, P]),
+    "vlg_attention_fwd_bf16": (I, [P, P, L, I, I, P]),
+    "vlg_attention_bwd_bf16": (I, [P, P, P, L, I, I, P]),
     "vlg_layout_loss_scratch": (I, []),
     "vlg_layout_loss": (I, [P, I, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, P]),
     "vlg_reduce_slabs": (I, [P, L, I, P, L, P]),
