@@ -93,15 +93,15 @@ int vlg_layernorm_bwd_bf16(const vlg_bf16* dy, const float* x, const float* mean
 #define VLG_EPI_BF16   16  /* operands rounded to bf16 for v_mfma_f32_32x32x16_bf16, fp32 accumulate and fp32
                               tensors in HBM (BASELINE.json configs[2]); default is exact-fp32 MFMA  */
 /* bf16 ACTIVATION STORAGE (with VLG_EPI_BF16 only): the activation operands named below are vlg_bf16 arrays in
- * HBM instead of float - half the bytes of a mode that is HBM-bound.  Weights, biases, gradient slabs and the
- * residual stream stay fp32; leading dimensions count elements.                                               */
+ * HBM instead of float - half the bytes of a mode that is HBM-bound.  Biases, gradient slabs, master weights and
+ * the residual stream stay fp32; leading dimensions count elements.                                             */
 #define VLG_EPI_A_BF16   32   /* first operand (A of fwd, dY of dgrad / wgrad) is bf16                          */
-#define VLG_EPI_B_BF16   64   /* wgrad: X is bf16                                                               */
+#define VLG_EPI_B_BF16   64   /* second operand is bf16: X of wgrad, W of fwd / dgrad (the shadow vlg_adam_step_bf16 keeps) */
 #define VLG_EPI_OUT_BF16 128  /* C and the epilogue's auxiliary operands (aux_in, aux_out) are bf16             */
-int vlg_linear_fwd(const void* A, int lda, const float* W, int ldw, const float* bias,
+int vlg_linear_fwd(const void* A, int lda, const void* W, int ldw, const float* bias,
                    void* C, int ldc, const void* aux_in, void* aux_out,
                    int64_t M, int N, int K, int epilogue, void* stream);
-int vlg_linear_dgrad(const void* dY, int ldy, const float* W, int ldw,
+int vlg_linear_dgrad(const void* dY, int ldy, const void* W, int ldw,
                      void* dX, int ldx, const void* aux_in,
                      int64_t M, int N, int K, int epilogue, void* stream);
 int vlg_linear_wgrad_slabs(int64_t M, int N, int K);                 /* slab count of a flags = 0 launch */
@@ -148,6 +148,10 @@ int vlg_reduce_slabs(const float* slabs, int64_t slab_stride, int n_slabs,
 int vlg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t n, int step, float lr, float beta1, float beta2, float eps,
                   float grad_scale, void* stream);
+/* same, and shadow[i] = bf16(param[i]) after the update: the weight operand of the bf16-MFMA projections */
+int vlg_adam_step_bf16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, vlg_bf16* shadow,
+                       int64_t n, int step, float lr, float beta1, float beta2, float eps,
+                       float grad_scale, void* stream);
 
 /* ---------------------------------------------------- reference-real image ops
  * Pixel-space ops of the reference step that exist verbatim in the reference.

@@ -323,28 +323,30 @@ def test_attention_bf16_storage(H, dev, T, d, n_seq):
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 768, 256), (333, 256, 1024)])
 def test_linear_bf16_storage(H, dev, M, N, K):
-    """Every (operand storage, epilogue) combination the bf16 step launches.  Weights are rounded to bf16 inside the
-    kernel (fragment read), so the fp64 reference uses bf16-rounded weights as well; outputs then differ from it by
-    fp32 accumulation noise and, for bf16 outputs, one final rounding."""
+    """Every (operand storage, epilogue) combination the bf16 step launches: bf16 activations and the bf16 shadow of the
+    weights (vlg_adam_step_bf16 keeps it), fp32 where the residual stream is involved.  The fp64 reference is computed
+    from the same bf16-representable values, so outputs differ from it by fp32 accumulation noise and, for bf16
+    outputs, one final rounding."""
     torch.manual_seed(13)
     FL = H.EPI_BF16
     a, w, bias = _bf(torch.randn(M, K)), _bf(torch.randn(N, K) / math.sqrt(K)), torch.randn(N)
-    ad, wd, bd = a.to(dev).to(BF), w.to(dev), bias.to(dev)
+    ad, wd, bd = a.to(dev).to(BF), w.to(dev).to(BF), bias.to(dev)
+    WB = H.EPI_B_BF16                                # the weight operand is the bf16 shadow
     ref = (a.double() @ w.double().t() + bias.double())
     # forward: bias -> bf16 (QKV), bias+gelu -> bf16 pair (FFN1), bias+resid -> fp32 (out-proj / FFN2)
     c = torch.zeros(M, N, device=dev, dtype=BF)
     H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, 0, M, N, K,
-           H.EPI_BIAS | FL | H.EPI_A_BF16 | H.EPI_OUT_BF16, stream())
+           H.EPI_BIAS | FL | H.EPI_A_BF16 | WB | H.EPI_OUT_BF16, stream())
     assert_close(c.float(), ref.float(), what="fwd bias (bf16 in/out)", **BF_OUT)
     u = torch.zeros(M, N, device=dev, dtype=BF)
     H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, u.data_ptr(), M, N, K,
-           H.EPI_BIAS | H.EPI_GELU | FL | H.EPI_A_BF16 | H.EPI_OUT_BF16, stream())
+           H.EPI_BIAS | H.EPI_GELU | FL | H.EPI_A_BF16 | WB | H.EPI_OUT_BF16, stream())
     assert_close(u.float(), ref.float(), what="fwd pre-activation (bf16)", **BF_OUT)
     assert_close(c.float(), F.gelu(ref).float(), what="fwd gelu (bf16)", rtol=2.0 ** -7, atol=2e-6)
     resid = torch.randn(M, N)
     rd, c32 = resid.to(dev), torch.zeros(M, N, device=dev)
     H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c32.data_ptr(), N, rd.data_ptr(), 0, M, N, K,
-           H.EPI_BIAS | H.EPI_RESID | FL | H.EPI_A_BF16, stream())
+           H.EPI_BIAS | H.EPI_RESID | FL | H.EPI_A_BF16 | WB, stream())
     assert_close(c32, (ref + resid.double()).float(), rtol=1e-4, atol=1e-5, what="fwd bias+resid (bf16 A, fp32 out)")
     # data gradient: dY fp32 or bf16 -> dX bf16; with gelu' of a bf16 pre-activation
     dy = _bf(torch.randn(M, N))
@@ -352,13 +354,13 @@ def test_linear_bf16_storage(H, dev, M, N, K):
     for dy_dev, bits, tag in ((dy.to(dev), 0, "fp32 dY"), (dy.to(dev).to(BF), H.EPI_A_BF16, "bf16 dY")):
         dx = torch.zeros(M, K, device=dev, dtype=BF)
         H.call("vlg_linear_dgrad", dy_dev.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, 0, M, N, K,
-               FL | bits | H.EPI_OUT_BF16, stream())
+               FL | bits | WB | H.EPI_OUT_BF16, stream())
         assert_close(dx.float(), dref.float(), what="dgrad -> bf16 (%s)" % tag, rtol=2.0 ** -7, atol=1e-5)
     pre = _bf(torch.randn(M, K))
     pd = pre.to(dev).to(BF)
     dx = torch.zeros(M, K, device=dev, dtype=BF)
     H.call("vlg_linear_dgrad", dy.to(dev).data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, pd.data_ptr(), M, N, K,
-           H.EPI_DGELU | FL | H.EPI_OUT_BF16, stream())
+           H.EPI_DGELU | FL | WB | H.EPI_OUT_BF16, stream())
     uu = pre.double().requires_grad_(True)
     F.gelu(uu).backward(dref)
     assert_close(dx.float(), uu.grad.float(), what="dgrad * gelu' (bf16 aux/out)", rtol=2.0 ** -7, atol=1e-5)
@@ -380,3 +382,22 @@ def test_linear_bf16_storage(H, dev, M, N, K):
     with pytest.raises(H.HipError):
         H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, 0, M, N, K,
                H.EPI_BIAS | H.EPI_A_BF16, stream())
+
+
+def test_adam_keeps_the_bf16_shadow(H, dev):
+    """vlg_adam_step_bf16 = vlg_adam_step + shadow[i] = round-to-nearest-even bf16 of the updated parameter."""
+    torch.manual_seed(14)
+    n = 4096 + 8
+    p0, g = torch.randn(n), torch.randn(n)
+    outs = []
+    for name in ("vlg_adam_step", "vlg_adam_step_bf16"):
+        p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        sh = torch.zeros(n, device=dev, dtype=BF)
+        gd = g.to(dev)
+        for step in (1, 2):
+            args = [p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr()] + ([sh.data_ptr()] if name.endswith("bf16") else []) + \
+                   [n, step, 2e-4, 0.5, 0.999, 1e-8, 1.0, stream()]
+            H.call(name, *args)
+        outs.append((p.cpu(), sh.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]), "the shadow variant must not change the fp32 update"
+    assert torch.equal(outs[1][1], outs[1][0].to(BF))

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--N", type=int, default=64)
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--bf16store", action="store_true", help="the bf16 mode's kernels with its HBM element types (GB/s shown)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = hip.load()
@@ -67,6 +68,35 @@ def main():
     add("attention bwd", 28.0 * M * d, "B", lambda: hip.call("vlg_attention_bwd", P(x_3d), P(x_d), P(y_3d), B * N, T, d, S))
     add("layernorm fwd", 8.0 * M * d, "B", lambda: hip.call("vlg_layernorm_fwd", P(x_d), P(g), P(g), P(y_d), P(stats[0]), P(stats[1]), M, d, 1e-5, S))
     add("layernorm bwd", 16.0 * M * d, "B", lambda: hip.call("vlg_layernorm_bwd", P(x_d), P(y_d), P(stats[0]), P(stats[1]), P(g), P(x_d), P(y_d), P(slabs), 2 * d, M, d, S))
+
+    if a.bf16store:
+        from vlg.hip import EPI_A_BF16 as AB, EPI_B_BF16 as BB, EPI_OUT_BF16 as OB, EPI_BF16 as FL
+        cases.clear()
+        bf = lambda t: t.to(torch.bfloat16)
+        hd, h3, hf, hf2 = bf(x_d), bf(x_3d), bf(x_ff), bf(x_ff2)          # bf16 activations
+        od, o3, of = bf(y_d), bf(y_3d), bf(y_ff)
+        by = lambda *terms: float(sum(terms))
+        E = M * d
+        add("fwd qkv  bf16->bf16", by(2 * E, 6 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(w_qkv), d, P(bias), P(o3), 3 * d, 0, 0, M, 3 * d, d, EPI_BIAS | FL | AB | OB, S))
+        add("fwd proj bf16->f32 +resid", by(2 * E, 4 * E, 4 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(w_proj), d, P(bias), P(y_d), d, P(x_d), 0, M, d, d, EPI_BIAS | EPI_RESID | FL | AB, S))
+        add("fwd ff1  bf16->2xbf16 gelu", by(2 * E, 16 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(w_ff1), d, P(bias), P(of), ff, 0, P(hf2), M, ff, d, EPI_BIAS | EPI_GELU | FL | AB | OB, S))
+        add("fwd ff2  bf16->f32 +resid", by(8 * E, 4 * E, 4 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hf), ff, P(w_ff2), ff, P(bias), P(y_d), d, P(x_d), 0, M, d, ff, EPI_BIAS | EPI_RESID | FL | AB, S))
+        wq16, wf16 = bf(w_qkv), bf(w_ff1)
+        add("fwd qkv  bf16->bf16 (bf16 W)", by(2 * E, 6 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(wq16), d, P(bias), P(o3), 3 * d, 0, 0, M, 3 * d, d, EPI_BIAS | FL | AB | BB | OB, S))
+        add("dgrad qkv  bf16->bf16 (bf16 W)", by(6 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(h3), 3 * d, P(wq16), d, P(od), d, 0, M, 3 * d, d, FL | AB | BB | OB, S))
+        add("dgrad ff1  bf16->bf16 (bf16 W)", by(8 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(hf), ff, P(wf16), d, P(od), d, 0, M, ff, d, FL | AB | BB | OB, S))
+        add("dgrad qkv  bf16->bf16", by(6 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(h3), 3 * d, P(w_qkv), d, P(od), d, 0, M, 3 * d, d, FL | AB | OB, S))
+        add("dgrad proj f32->bf16", by(4 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_proj), d, P(od), d, 0, M, d, d, FL | OB, S))
+        add("dgrad ff1  bf16->bf16", by(8 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(hf), ff, P(w_ff1), d, P(od), d, 0, M, ff, d, FL | AB | OB, S))
+        add("dgrad ff2  f32->bf16 dgelu", by(4 * E, 8 * E, 8 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(of), ff, P(hf2), M, d, ff, EPI_DGELU | FL | OB, S))
+        for nm, n, k, dy, xx, bits, nb in (("qkv  bf16,bf16", 3 * d, d, h3, hd, AB | BB, by(6 * E, 2 * E)), ("proj f32,bf16", d, d, y_d, hd, BB, by(4 * E, 2 * E)),
+                                           ("ff1  bf16,bf16", ff, d, hf, hd, AB | BB, by(8 * E, 2 * E)), ("ff2  f32,bf16", d, ff, x_d, hf, BB, by(4 * E, 8 * E))):
+            ns = lib.vlg_linear_wgrad_slabs_for(M, n, k, FL)
+            add("wgrad %s (%d slabs)" % (nm, ns), nb + 4.0 * ns * (n * k + n), "B", lambda n=n, k=k, dy=dy, xx=xx, bits=bits: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, M, n, k, FL | bits, S))
+        add("attention fwd bf16", 8.0 * M * d, "B", lambda: hip.call("vlg_attention_fwd_bf16", P(h3), P(od), B * N, T, d, S))
+        add("attention bwd bf16", 14.0 * M * d, "B", lambda: hip.call("vlg_attention_bwd_bf16", P(h3), P(hd), P(o3), B * N, T, d, S))
+        add("layernorm fwd ->bf16", 6.0 * M * d, "B", lambda: hip.call("vlg_layernorm_fwd_bf16", P(x_d), P(g), P(g), P(od), P(stats[0]), P(stats[1]), M, d, 1e-5, S))
+        add("layernorm bwd bf16 dy", 14.0 * M * d, "B", lambda: hip.call("vlg_layernorm_bwd_bf16", P(hd), P(y_d), P(stats[0]), P(stats[1]), P(g), P(x_d), P(x_d), P(slabs), 2 * d, M, d, S))
 
     times = {c[0]: [] for c in cases}
     for rnd in range(a.rounds + 1):

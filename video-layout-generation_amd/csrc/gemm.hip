@@ -243,7 +243,7 @@ static int gemm_io_bits(int flags) {
 
 static bool gemm_ptr_ok(const void* p, int ld) { return vlg_aligned16(p) && (ld & 3) == 0; }
 
-extern "C" int vlg_linear_fwd(const void* A, int lda, const float* W, int ldw, const float* bias,
+extern "C" int vlg_linear_fwd(const void* A, int lda, const void* W, int ldw, const float* bias,
                               void* C, int ldc, const void* aux_in, void* aux_out,
                               int64_t M, int N, int K, int epilogue, void* stream) {
     if (M < 1 || N < 1 || K < 4 || (K & 3) || lda < K || ldw < K || ldc < N) return VLG_ERR_SHAPE;
@@ -261,7 +261,7 @@ extern "C" int vlg_linear_fwd(const void* A, int lda, const float* W, int ldw, c
     if ((epilogue & VLG_EPI_GELU) && !aux_out) return VLG_ERR_SHAPE;
     const bool narrow = N <= 32;
     if (io != 0 && !bf16) return VLG_ERR_SHAPE;      // bf16 activation storage exists for the bf16 MFMA mode only
-    if ((io & 1) && (lda & 7)) return VLG_ERR_ALIGN;
+    if (((io & 1) && (lda & 7)) || ((io & 2) && (ldw & 7))) return VLG_ERR_ALIGN;
     if (bf16) return vlg_gemm16_fwd(g, epilogue, io, s);
     switch (epilogue) {
         case VLG_EPI_BIAS:
@@ -276,7 +276,7 @@ extern "C" int vlg_linear_fwd(const void* A, int lda, const float* W, int ldw, c
     }
 }
 
-extern "C" int vlg_linear_dgrad(const void* dY, int ldy, const float* W, int ldw, void* dX, int ldx,
+extern "C" int vlg_linear_dgrad(const void* dY, int ldy, const void* W, int ldw, void* dX, int ldx,
                                 const void* aux_in, int64_t M, int N, int K, int epilogue, void* stream) {
     // dX[M,K] = dY[M,N] . W[N,K]  : contraction over N, W is contraction-major
     if (M < 1 || N < 4 || (N & 3) || K < 4 || (K & 3) || ldy < N || ldw < K || ldx < K) return VLG_ERR_SHAPE;
@@ -290,7 +290,7 @@ extern "C" int vlg_linear_dgrad(const void* dY, int ldy, const float* W, int ldw
     const int io = gemm_io_bits(epilogue);
     epilogue &= ~(VLG_EPI_BF16 | VLG_EPI_STORAGE);
     if (io != 0 && !bf16) return VLG_ERR_SHAPE;
-    if ((io & 1) && (ldy & 7)) return VLG_ERR_ALIGN;
+    if (((io & 1) && (ldy & 7)) || ((io & 2) && (ldw & 7))) return VLG_ERR_ALIGN;
     if (epilogue == VLG_EPI_DGELU && !aux_in) return VLG_ERR_SHAPE;
     if (bf16) return vlg_gemm16_dgrad(g, epilogue, io, s);
     switch (epilogue) {

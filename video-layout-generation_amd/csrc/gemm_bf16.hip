@@ -20,11 +20,11 @@
 #include "common.h"
 #include <type_traits>
 #include "gemm_tile.h"
+#include <stdlib.h>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-#define BK16 64
 
 // pack 8 fp32 values (two float4) into 8 bf16 (round to nearest even)
 __device__ __forceinline__ uint4 pack_bf16x8(float4 a, float4 b) {
@@ -37,7 +37,7 @@ template <typename E, int NV> struct Stage16;
 template <int NV> struct Stage16<bf16_t, NV> { uint4 v[NV]; };
 template <int NV> struct Stage16<float, NV> { float4 lo[NV], hi[NV]; };
 
-template <int BR, bool KC>
+template <int BR, bool KC, int BK16>
 struct Tile16 {
     static constexpr int RS = KC ? BK16 + 8 : BR + 32;                   // row stride of the LDS image, elements
     static constexpr int ELEMS = KC ? BR * RS : BK16 * RS;
@@ -121,8 +121,12 @@ struct Tile16 {
     }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, typename EA, typename EB, typename EO>
+template <int BM, int BN, int BK16, bool A_KC, bool B_KC, int EPI, bool COLSUM, typename EA, typename EB, typename EO>
 __device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
+    constexpr int DEPTH = BK16 == 64 ? 2 : 1;          // register-resident tiles in flight besides the two LDS buffers
+    // (a 32-deep, DEPTH 1, 4-blocks-per-CU instantiation was measured: +4 % on forward / data gradient, -30 % on the
+    // weight gradient whose column-sum registers then spill - not kept)
+    constexpr int NS = BK16 / 16;                      // 16-deep MFMA steps per tile
     static_assert(!COLSUM || !A_KC, "column sums are taken from a contraction-major A tile");
     const EA* const gA = static_cast<const EA*>(g.A);
     const EB* const gB = static_cast<const EB*>(g.B);
@@ -131,8 +135,8 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
     constexpr int WM = (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 4 : 1);
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-    using TA = Tile16<BM, A_KC>;
-    using TB = Tile16<BN, B_KC>;
+    using TA = Tile16<BM, A_KC, BK16>;
+    using TB = Tile16<BN, B_KC, BK16>;
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (TA::ELEMS + TB::ELEMS)];
     bf16_t* const As0 = smem;
     bf16_t* const Bs0 = smem + 2 * TA::ELEMS;
@@ -202,16 +206,16 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
             const int cur = kt & 1;
             const bf16_t* as = As0 + cur * TA::ELEMS;
             const bf16_t* bs = Bs0 + cur * TB::ELEMS;
-            kstep(as, bs, 0);
-            kstep(as, bs, 1);
+#pragma unroll
+            for (int ks = 0; ks < NS / 2; ++ks) kstep(as, bs, ks);
             if (kt + 1 < nk) {
                 if constexpr (COLSUM) { if (tn == 0) TA::colsum_add(csum, xa); }
                 TA::sstore(xa, As0 + (cur ^ 1) * TA::ELEMS, tid);
                 TB::sstore(xb, Bs0 + (cur ^ 1) * TB::ELEMS, tid);
             }
-            if (kt + 3 < nk) load(xa, xb, kt + 3);
-            kstep(as, bs, 2);
-            kstep(as, bs, 3);
+            if (kt + 1 + DEPTH < nk) load(xa, xb, kt + 1 + DEPTH);
+#pragma unroll
+            for (int ks = NS / 2; ks < NS; ++ks) kstep(as, bs, ks);
             __syncthreads();
         };
         if (nk > 0) {
@@ -221,11 +225,17 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
             TB::sstore(sb0, Bs0, tid);
         }
         if (nk > 1) load(sa0, sb0, 1);
-        if (nk > 2) load(sa1, sb1, 2);
+        if constexpr (DEPTH == 2) {
+            if (nk > 2) load(sa1, sb1, 2);
+        }
         __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {            // tile kt+1 sits in (sa0, sb0) on even, in (sa1, sb1) on odd iterations
-            iter(kt, sa0, sb0);
-            if (kt + 1 < nk) iter(kt + 1, sa1, sb1);
+        if constexpr (DEPTH == 2) {
+            for (int kt = 0; kt < nk; kt += 2) {        // tile kt+1 sits in (sa0, sb0) on even, in (sa1, sb1) on odd iterations
+                iter(kt, sa0, sb0);
+                if (kt + 1 < nk) iter(kt + 1, sa1, sb1);
+            }
+        } else {
+            for (int kt = 0; kt < nk; ++kt) iter(kt, sa0, sb0);
         }
     };
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) % BK16) == 0);
@@ -266,6 +276,8 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
                 }
             }
     };
+    // (An LDS-staged epilogue for bf16 outputs - column pairs packed with a DPP swap, 16-byte row-contiguous stores - was
+    // measured and is NOT faster than these 2-byte stores: the kernels are not bound by store requests.)
     if (full) emit(std::false_type{});
     else emit(std::true_type{});
     if constexpr (COLSUM) {
@@ -297,9 +309,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
     using EA = std::conditional_t<(IO & 1) != 0, bf16_t, float>;
     using EB = std::conditional_t<(IO & 2) != 0, bf16_t, float>;
     using EO = std::conditional_t<(IO & 4) != 0, bf16_t, float>;
-    gemm16_body<BM, BN, A_KC, B_KC, EPI, COLSUM, EA, EB, EO>(g);
+    gemm16_body<BM, BN, 64, A_KC, B_KC, EPI, COLSUM, EA, EB, EO>(g);
 }
-
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, int IO>
 static int launch16(GemmArgs g, hipStream_t s) {
     g.tiles_m = (int)((g.M + BM - 1) / BM);
@@ -312,43 +323,46 @@ static int launch16(GemmArgs g, hipStream_t s) {
 }
 
 // Entry points for gemm.hip's C ABI functions.  `io` = storage bits (see gemm_bf16_kernel); shapes were validated by the
-// caller, this layer adds the 8-element granularity of the bf16 slots.
+// caller, this layer adds the 8-element granularity of the bf16 slots.  Instantiated: everything fp32 (io 0, the
+// "bf16_mfma" mode) and the combinations the bf16-storage step launches (bf16 activations AND bf16 shadow weights).
 int vlg_gemm16_fwd(GemmArgs g, int epilogue, int io, hipStream_t s) {
-    if ((g.Kc & 7) || (g.lda & 7 && (io & 1)) || (g.lda & 3) || (g.ldb & 3)) return VLG_ERR_SHAPE;
+    if ((io & 4) && ((g.ldc & 7) || !vlg_aligned16(g.C) || (g.aux_out && !vlg_aligned16(g.aux_out)))) return VLG_ERR_ALIGN;
+    if (g.Kc & 7) return VLG_ERR_SHAPE;
     const bool narrow = g.N <= 32;
 #define FWD(EPI, IO) (narrow ? launch16<128, 32, true, true, EPI, false, IO>(g, s) : launch16<128, 128, true, true, EPI, false, IO>(g, s))
     if (epilogue == VLG_EPI_BIAS) {
-        switch (io) { case 0: return FWD(VLG_EPI_BIAS, 0); case 1: return FWD(VLG_EPI_BIAS, 1); case 5: return FWD(VLG_EPI_BIAS, 5); default: return VLG_ERR_SHAPE; }
+        switch (io) { case 0: return FWD(VLG_EPI_BIAS, 0); case 3: return FWD(VLG_EPI_BIAS, 3); case 7: return FWD(VLG_EPI_BIAS, 7); default: return VLG_ERR_SHAPE; }
     }
+#undef FWD
     if (narrow) return VLG_ERR_SHAPE;
     if (epilogue == (VLG_EPI_BIAS | VLG_EPI_GELU)) {
         if (io == 0) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false, 0>(g, s);
-        if (io == 5) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false, 5>(g, s);
+        if (io == 7) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false, 7>(g, s);
         return VLG_ERR_SHAPE;
     }
     if (epilogue == (VLG_EPI_BIAS | VLG_EPI_RESID)) {
         if (io == 0) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false, 0>(g, s);
-        if (io == 1) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false, 1>(g, s);
+        if (io == 3) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false, 3>(g, s);
         return VLG_ERR_SHAPE;
     }
-#undef FWD
     return VLG_ERR_SHAPE;
 }
 
 int vlg_gemm16_dgrad(GemmArgs g, int epilogue, int io, hipStream_t s) {
     // contraction over N (g.Kc), W rows are K-contiguous: both extents in 8-element slots
+    if ((io & 4) && ((g.ldc & 7) || !vlg_aligned16(g.C))) return VLG_ERR_ALIGN;
     if ((g.Kc & 7) || (g.N & 7)) return VLG_ERR_SHAPE;
     if (epilogue == VLG_EPI_NONE) {
         switch (io) {
             case 0: return launch16<128, 128, true, false, VLG_EPI_NONE, false, 0>(g, s);
-            case 4: return launch16<128, 128, true, false, VLG_EPI_NONE, false, 4>(g, s);
-            case 5: return launch16<128, 128, true, false, VLG_EPI_NONE, false, 5>(g, s);
+            case 6: return launch16<128, 128, true, false, VLG_EPI_NONE, false, 6>(g, s);
+            case 7: return launch16<128, 128, true, false, VLG_EPI_NONE, false, 7>(g, s);
             default: return VLG_ERR_SHAPE;
         }
     }
     if (epilogue == VLG_EPI_DGELU) {
         if (io == 0) return launch16<128, 128, true, false, VLG_EPI_DGELU, false, 0>(g, s);
-        if (io == 4) return launch16<128, 128, true, false, VLG_EPI_DGELU, false, 4>(g, s);
+        if (io == 6) return launch16<128, 128, true, false, VLG_EPI_DGELU, false, 6>(g, s);
         return VLG_ERR_SHAPE;
     }
     return VLG_ERR_SHAPE;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_tall_kernel(const float* __r
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                    float beta1, float beta2, float eps, float step_size,
-                                                   float sqrt_bc2, float grad_scale) {
+                                                   float sqrt_bc2, float grad_scale, bf16_t* __restrict__ shadow) {
     const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
     (void)beta1;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, co
             pp[k] -= step_size * (mp[k] / denom);
         }
         st4(param + e * 4, p); st4(m + e * 4, mm); st4(v + e * 4, vv);
+        if (shadow != nullptr) st4(shadow + e * 4, p);         // bf16 copy of the updated weights for the bf16-MFMA projections
     }
 }
 
@@ -100,18 +101,31 @@ extern "C" int vlg_reduce_slabs(const float* slabs, int64_t slab_stride, int n_s
     return vlg_last_error();
 }
 
-extern "C" int vlg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                             int step, float lr, float beta1, float beta2, float eps, float grad_scale,
-                             void* stream) {
+static int adam_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, bf16_t* shadow, int64_t n,
+                       int step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
     if (n < 4 || (n & 3) || step < 1) return VLG_ERR_SHAPE;
-    if (!vlg_aligned16(param) || !vlg_aligned16(grad) || !vlg_aligned16(exp_avg) || !vlg_aligned16(exp_avg_sq))
-        return VLG_ERR_ALIGN;
+    if (!vlg_aligned16(param) || !vlg_aligned16(grad) || !vlg_aligned16(exp_avg) || !vlg_aligned16(exp_avg_sq) ||
+        (shadow && !vlg_aligned8(shadow))) return VLG_ERR_ALIGN;
     // bias corrections in double, as torch.optim.Adam computes them on the host
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float sqrt_bc2 = (float)sqrt(bc2);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       exp_avg, exp_avg_sq, n / 4, beta1, beta2, eps, step_size, sqrt_bc2, grad_scale);
+                       exp_avg, exp_avg_sq, n / 4, beta1, beta2, eps, step_size, sqrt_bc2, grad_scale, shadow);
     return vlg_last_error();
+}
+
+extern "C" int vlg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             int step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                             void* stream) {
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, nullptr, n, step, lr, beta1, beta2, eps, grad_scale, stream);
+}
+
+extern "C" int vlg_adam_step_bf16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                  vlg_bf16* shadow, int64_t n, int step, float lr, float beta1, float beta2,
+                                  float eps, float grad_scale, void* stream) {
+    if (!shadow) return VLG_ERR_SHAPE;
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, reinterpret_cast<bf16_t*>(shadow), n, step, lr, beta1, beta2, eps,
+                       grad_scale, stream);
 }

@@ -90,6 +90,8 @@ class LayoutEngine:
         self.exp_avg = torch.zeros(self.n_params, **f32)
         self.exp_avg_sq = torch.zeros(self.n_params, **f32)
         self.step_count = 0
+        # bf16 mode: a bf16 copy of the weights feeds the projections (the Adam kernel refreshes it with every update)
+        self.params_bf16 = torch.zeros(self.n_params, dtype=torch.bfloat16, device=device) if self.bf16_store else None
         self.load_params(init_params(cfg, seed))
         self._alloc_workspace(cfg.tokens)
         self.loss_out = self.grads_ext[self.n_params:]   # {total, smooth_l1, iou, ce}
@@ -103,12 +105,21 @@ class LayoutEngine:
     def p(self, name: str) -> torch.Tensor:
         return self.view(self.params, name)
 
+    def pw(self, name: str) -> torch.Tensor:
+        """weight operand of a projection: the fp32 master, or its bf16 shadow in the bf16 mode"""
+        return self.view(self.params_bf16 if self.bf16_store else self.params, name)
+
+    def _refresh_shadow(self) -> None:
+        if self.params_bf16 is not None:
+            self.params_bf16.copy_(self.params)          # round to nearest even, as the Adam kernel does
+
     def g(self, name: str) -> torch.Tensor:
         return self.view(self.grads, name)
 
     def load_params(self, tensors: Dict[str, torch.Tensor]) -> None:
         for name in self.layout:
             self.p(name).copy_(tensors[name].to(torch.float32))
+        self._refresh_shadow()
 
     def named_params(self) -> Dict[str, torch.Tensor]:
         return {n: self.p(n) for n in self.layout}
@@ -125,6 +136,7 @@ class LayoutEngine:
         if tuple(sd["params"].shape) != (self.n_params,):
             raise ValueError("checkpoint has %d parameters, model has %d" % (sd["params"].numel(), self.n_params))
         self.params.copy_(sd["params"])
+        self._refresh_shadow()
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
@@ -195,15 +207,15 @@ class LayoutEngine:
                 (EPI_OUT_BF16 if out is not None and out.dtype == bf else 0))
 
     def _linear(self, a, w, b, c, M, N, K, epi, aux_in=None, aux_out=None):
-        nb = (a.element_size() * M * K + 4.0 * N * K +
+        nb = (a.element_size() * M * K + w.element_size() * N * K +
               c.element_size() * M * N * (1 + (aux_in is not None) + (aux_out is not None)))
-        flags = epi | self.gemm_flags | self._storage_bits(a, None, c)
+        flags = epi | self.gemm_flags | self._storage_bits(a, w, c)
         self._timed("gemm_fwd" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_fwd", ptr(a), K, ptr(w), K,
                     ptr(b), ptr(c), N, ptr(aux_in), ptr(aux_out), M, N, K, flags, self._stream(), nbytes=nb)
 
     def _dgrad(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux_in=None):
-        nb = dy.element_size() * M * N + 4.0 * N * K + dx.element_size() * M * K * (1 + (aux_in is not None))
-        flags = epi | self.gemm_flags | self._storage_bits(dy, None, dx)
+        nb = dy.element_size() * M * N + w.element_size() * N * K + dx.element_size() * M * K * (1 + (aux_in is not None))
+        flags = epi | self.gemm_flags | self._storage_bits(dy, w, dx)
         self._timed("gemm_dgrad", 2.0 * M * N * K, "vlg_linear_dgrad", ptr(dy), N, ptr(w), K, ptr(dx), K,
                     ptr(aux_in), M, N, K, flags, self._stream(), nbytes=nb)
 
@@ -264,18 +276,18 @@ class LayoutEngine:
             pre = "l%d." % l
             x = self.x[l]
             self._ln_fwd(x, pre + "ln1_g", self.h1[l], self.stats[2 * l], M)
-            self._linear(self.h1[l], self.p(pre + "qkv_w"), self.p(pre + "qkv_b"), self.qkv[l], M, 3 * d, d, EPI_BIAS)
+            self._linear(self.h1[l], self.pw(pre + "qkv_w"), self.p(pre + "qkv_b"), self.qkv[l], M, 3 * d, d, EPI_BIAS)
             call("vlg_attention_fwd" + self._sfx, ptr(self.qkv[l]), ptr(self.att[l]), B * N, T, d, s)
-            self._linear(self.att[l], self.p(pre + "proj_w"), self.p(pre + "proj_b"), self.xmid[l], M, d, d,
+            self._linear(self.att[l], self.pw(pre + "proj_w"), self.p(pre + "proj_b"), self.xmid[l], M, d, d,
                          EPI_BIAS | EPI_RESID, aux_in=x)
             self._ln_fwd(self.xmid[l], pre + "ln2_g", self.h2[l], self.stats[2 * l + 1], M)
-            self._linear(self.h2[l], self.p(pre + "ff1_w"), self.p(pre + "ff1_b"), self.gl[l], M, ff, d,
+            self._linear(self.h2[l], self.pw(pre + "ff1_w"), self.p(pre + "ff1_b"), self.gl[l], M, ff, d,
                          EPI_BIAS | EPI_GELU, aux_out=self.u[l])
-            self._linear(self.gl[l], self.p(pre + "ff2_w"), self.p(pre + "ff2_b"), self.x[l + 1], M, d, ff,
+            self._linear(self.gl[l], self.pw(pre + "ff2_w"), self.p(pre + "ff2_b"), self.x[l + 1], M, d, ff,
                          EPI_BIAS | EPI_RESID, aux_in=self.xmid[l])
         L = cfg.n_layers
         self._ln_fwd(self.x[L], "lnf_g", self.xf, self.stats[2 * L], M)
-        self._linear(self.xf, self.p("head_w"), self.p("head_b"), self.out, M, cfg.n_out, d, EPI_BIAS)
+        self._linear(self.xf, self.pw("head_w"), self.p("head_b"), self.out, M, cfg.n_out, d, EPI_BIAS)
         call("vlg_layout_loss", ptr(self.out), cfg.n_out, ptr(batch["tgt_class"]), ptr(batch["tgt_box"]),
              ptr(batch["valid"]), ptr(self.dout), ptr(self.loss_out), ptr(self.loss_scratch), B, T, N,
              cfg.n_classes, SMOOTH_L1_BETA, IOU_EPS, LOSS_W_REG, LOSS_W_STRUCT, LOSS_W_CE, s)
@@ -291,7 +303,7 @@ class LayoutEngine:
         s = self._stream()
         L = cfg.n_layers
         self._wgrad(self.dout, self.xf, "head_w", M, cfg.n_out, d)
-        self._dgrad(self.dout, self.p("head_w"), self.dh, M, cfg.n_out, d)
+        self._dgrad(self.dout, self.pw("head_w"), self.dh, M, cfg.n_out, d)
         self._ln_bwd(self.dh, self.x[L], self.stats[2 * L], "lnf_g", None, self.dx, M)
         if reducer is not None:
             reducer.ready("head")
@@ -299,16 +311,16 @@ class LayoutEngine:
             pre = "l%d." % l
             # FFN:  x_out = xmid + W2 gelu(W1 h2 + b1) + b2
             self._wgrad(self.dx, self.gl[l], pre + "ff2_w", M, d, ff)
-            self._dgrad(self.dx, self.p(pre + "ff2_w"), self.du, M, d, ff, EPI_DGELU, aux_in=self.u[l])
+            self._dgrad(self.dx, self.pw(pre + "ff2_w"), self.du, M, d, ff, EPI_DGELU, aux_in=self.u[l])
             self._wgrad(self.du, self.h2[l], pre + "ff1_w", M, ff, d)
-            self._dgrad(self.du, self.p(pre + "ff1_w"), self.dh, M, ff, d)
+            self._dgrad(self.du, self.pw(pre + "ff1_w"), self.dh, M, ff, d)
             self._ln_bwd(self.dh, self.xmid[l], self.stats[2 * l + 1], pre + "ln2_g", self.dx, self.dx, M)
             # attention:  xmid = x + Wo attn(Wqkv h1 + b) + bo
             self._wgrad(self.dx, self.att[l], pre + "proj_w", M, d, d)
-            self._dgrad(self.dx, self.p(pre + "proj_w"), self.dh, M, d, d)
+            self._dgrad(self.dx, self.pw(pre + "proj_w"), self.dh, M, d, d)
             call("vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s)
             self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d)
-            self._dgrad(self.dqkv, self.p(pre + "qkv_w"), self.dh, M, 3 * d, d)
+            self._dgrad(self.dqkv, self.pw(pre + "qkv_w"), self.dh, M, 3 * d, d)
             self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)
             if reducer is not None:
                 reducer.ready("l%d" % l)
@@ -349,6 +361,11 @@ class LayoutEngine:
         if advance:
             self.step_count += 1
         o = 4 * lo
+        if self.params_bf16 is not None:
+            call("vlg_adam_step_bf16", self.params.data_ptr() + o, self.grads.data_ptr() + o, self.exp_avg.data_ptr() + o,
+                 self.exp_avg_sq.data_ptr() + o, self.params_bf16.data_ptr() + o // 2, hi - lo, self.step_count, self.lr,
+                 self.beta1, ADAM_BETA2, ADAM_EPS, grad_scale, self._stream())
+            return
         call("vlg_adam_step", self.params.data_ptr() + o, self.grads.data_ptr() + o, self.exp_avg.data_ptr() + o,
              self.exp_avg_sq.data_ptr() + o, hi - lo, self.step_count, self.lr, self.beta1, ADAM_BETA2, ADAM_EPS,
              grad_scale, self._stream())

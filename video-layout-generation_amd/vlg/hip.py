@@ -44,6 +44,7 @@ SIGNATURES = {
     "vlg_layout_loss": (I, [P, I, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, P]),
     "vlg_reduce_slabs": (I, [P, L, I, P, L, P]),
     "vlg_adam_step": (I, [P, P, P, P, L, I, F, F, F, F, F, P]),
+    "vlg_adam_step_bf16": (I, [P, P, P, P, P, L, I, F, F, F, F, F, P]),
     "vlg_image_loss_scratch": (I, []),
     "vlg_ce_nchw": (I, [P, P, P, P, P, I, I, L, F, P]),
     "vlg_l1_mean": (I, [P, P, P, P, P, L, F, P]),
