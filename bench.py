@@ -37,6 +37,12 @@ KERNEL_OF_FAMILY = {             # rocprofv3 kernel names (profiles/) for each t
     "gemm_wgrad": "gemm_f32_kernel<128,128,32,false,false,0,true>",
     "gemm_head": "gemm_f32_kernel<128,32,32,..>/<32,128,32,..>",
 }
+KERNEL_OF_FAMILY_X3 = {          # --dtype f32x3 (csrc/gemm_split.hip)
+    "gemm_fwd": "gemm_split_kernel<128,128,true,true,*,false>",
+    "gemm_dgrad": "gemm_split_kernel<128,128,true,false,*,false>",
+    "gemm_wgrad": "gemm_split_kernel<128,128,false,false,0,true>",
+    "gemm_head": "gemm_split_kernel<128,32,..>/<32,128,..>",
+}
 KERNEL_OF_FAMILY_BF16 = {        # --dtype bf16: bf16 LDS tiles, 64-deep, IO = storage bits (csrc/gemm_bf16.hip)
     "gemm_fwd": "gemm_bf16_kernel<128,128,true,true,*,false,IO>",
     "gemm_dgrad": "gemm_bf16_kernel<128,128,true,false,*,false,IO>",
@@ -88,8 +94,9 @@ def main():
     ap.add_argument("--N", type=int, default=64)
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32 (default): exact-fp32 MFMA projections, parity 1e-4; bf16: BASELINE configs[2] mode")
+    ap.add_argument("--dtype", choices=["f32", "f32x3", "bf16"], default="f32",
+                    help="f32 (default): native fp32 MFMA projections, parity 1e-4; f32x3: fp32 tensors, projections on the "
+                         "bf16 matrix cores from exact 3-way operand splits (same 1e-4 parity); bf16: BASELINE configs[2] mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -116,7 +123,7 @@ def main():
     from vlg.spec import LayoutConfig, SEED, step_flops
 
     cfg = LayoutConfig(B=args.B, T=args.T, N=args.N, d=args.d, n_layers=args.layers)
-    eng = LayoutEngine(cfg, dev, seed=SEED, precision="bf16" if args.dtype == "bf16" else "fp32")   # same seed on every rank (main.py:57-60)
+    eng = LayoutEngine(cfg, dev, seed=SEED, precision={"f32": "fp32", "f32x3": "fp32x3", "bf16": "bf16"}[args.dtype])   # same seed on every rank (main.py:57-60)
     batch = to_device(synthetic_clips(cfg.B, cfg.T, cfg.N, seed=SEED + rank), dev)   # each rank its own clips
     reducer = None
     force = os.environ.get("VLG_FORCE_COMM", "0") == "1"      # 1-GPU rehearsal of the RCCL path (torchrun, world size 1)
@@ -184,6 +191,10 @@ def main():
                 with open(tpath) as f:
                     traffic = json.load(f).get(fam)
             bound, peak, unit = "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+            if args.dtype == "f32x3":
+                # six bf16 MFMAs stand for one fp32 product block: price the ALGORITHMIC flops against the bf16 peak / 6
+                peak = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+                traffic = None                     # the committed PMC pass was taken in f32 mode
             if args.dtype == "bf16":
                 # with 16x faster MFMAs the same kernel is bound by moving its operands: price it against HBM
                 # (algorithmic bytes: both operands once + the slabs written)
@@ -193,7 +204,7 @@ def main():
             roof = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(s["bytes_per_launch"]),
-                    "kernel": (KERNEL_OF_FAMILY_BF16 if args.dtype == "bf16" else KERNEL_OF_FAMILY)[fam], "launches": s["launches"],
+                    "kernel": {"bf16": KERNEL_OF_FAMILY_BF16, "f32x3": KERNEL_OF_FAMILY_X3, "f32": KERNEL_OF_FAMILY}[args.dtype][fam], "launches": s["launches"],
                     "avg_launch_us": round(1e3 * s["avg_ms"], 2),
                     "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
                     "share_of_step": round(s["total_ms"] / (1e3 * elapsed), 4),
@@ -203,23 +214,31 @@ def main():
                                               for k, v in allf.items()}}
         line["roofline"] = roof
         if args.dtype == "f32" and world == 1:
-            # informational: the same step with bf16 MFMA projections (BASELINE.json configs[2]); `value` stays f32
-            e2 = LayoutEngine(cfg, dev, seed=SEED, precision="bf16")
-            for _ in range(3):
-                e2.train_step(batch)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                e2.train_step(batch)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / 10
-            line["bf16_projections"] = {"value": round(cfg.B / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt, 4),
-                                        "note": "v_mfma_f32_32x32x16_bf16 projections (fp32 accumulate) with the projection-side "
-                                                "activations and their gradients stored as bf16 in HBM; residual stream, "
-                                                "statistics, softmax, losses, weight gradients, Adam fp32; loss within 2e-2 "
-                                                "of fp32 (tests/test_hip_step.py)",
-                                        "final_loss": round(float(e2.loss_out[0]), 5)}
-            del e2
+            # informational: the same step in the two other projection modes; `value` stays native fp32
+            notes = {
+                "bf16": ("bf16_projections",
+                         "BASELINE.json configs[2]: v_mfma_f32_32x32x16_bf16 projections (fp32 accumulate) with the projection-side "
+                         "activations and their gradients stored as bf16 in HBM and a bf16 weight shadow; residual stream, "
+                         "statistics, softmax, losses, weight gradients, Adam fp32; loss within 2e-2 of fp32 "
+                         "(tests/test_hip_step.py)"),
+                "fp32x3": ("f32x3_projections",
+                           "fp32 tensors, fp32-grade projections on the bf16 matrix cores: operands split exactly into three bf16 "
+                           "terms, six bf16 MFMAs per product block, fp32 accumulate (csrc/gemm_split.hip); passes the same 1e-4 "
+                           "parity tests as the native fp32 path, error vs fp64 within 4x of it (tests/test_hip_ops.py)"),
+            }
+            for prec, (key, note) in notes.items():
+                e2 = LayoutEngine(cfg, dev, seed=SEED, precision=prec)
+                for _ in range(3):
+                    e2.train_step(batch)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    e2.train_step(batch)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 10
+                line[key] = {"value": round(cfg.B / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt, 4),
+                             "note": note, "final_loss": round(float(e2.loss_out[0]), 5)}
+                del e2
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         else:

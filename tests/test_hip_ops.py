@@ -401,3 +401,63 @@ def test_adam_keeps_the_bf16_shadow(H, dev):
         outs.append((p.cpu(), sh.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]), "the shadow variant must not change the fp32 update"
     assert torch.equal(outs[1][1], outs[1][0].to(BF))
+
+
+# ------------------------------------------------ fp32 on the bf16 matrix cores (3-way split, csrc/gemm_split.hip)
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 768, 256), (333, 256, 1024), (1000, 24, 256)])
+def test_linear_split3_is_fp32_grade(H, dev, M, N, K):
+    """VLG_EPI_SPLIT3: fp32 tensors, each operand split exactly into three bf16 terms, six bf16 MFMAs per product block.
+    Same 1e-4 parity bar as the native fp32 MFMA path, and its error against fp64 must stay within 4x of the native
+    path's (it is typically about equal: both round every accumulation step to fp32)."""
+    torch.manual_seed(15)
+    S3 = H.EPI_SPLIT3
+    a, w, bias = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    ref = a.double() @ w.double().t() + bias.double()
+    err = {}
+    for tag, fl in (("native", 0), ("split", S3)):
+        c = torch.zeros(M, N, device=dev)
+        H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, 0, M, N, K,
+               H.EPI_BIAS | fl, stream())
+        assert_close(c, ref.float(), rtol=1e-4, atol=1e-5, what="fwd bias (%s)" % tag)
+        err[tag] = float((c.cpu().double() - ref).abs().max())
+    assert err["split"] <= 4 * err["native"] + 1e-7, err
+    if N > 32:
+        u, c = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev)
+        H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, u.data_ptr(), M, N, K,
+               H.EPI_BIAS | H.EPI_GELU | S3, stream())
+        assert_close(u, ref.float(), rtol=1e-4, atol=1e-5, what="split fwd pre-activation")
+        assert_close(c, F.gelu(ref).float(), rtol=1e-4, atol=1e-5, what="split fwd gelu")
+        resid = torch.randn(M, N)
+        rd = resid.to(dev)
+        H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, rd.data_ptr(), 0, M, N, K,
+               H.EPI_BIAS | H.EPI_RESID | S3, stream())
+        assert_close(c, (ref + resid.double()).float(), rtol=1e-4, atol=1e-5, what="split fwd bias+resid")
+    if N % 8:
+        return
+    dy = torch.randn(M, N)
+    dyd = dy.to(dev)
+    dref = dy.double() @ w.double()
+    dx = torch.zeros(M, K, device=dev)
+    H.call("vlg_linear_dgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, 0, M, N, K, S3, stream())
+    assert_close(dx, dref.float(), rtol=1e-4, atol=1e-5, what="split dgrad")
+    if N > 32:
+        pre = torch.randn(M, K)
+        pd = pre.to(dev)
+        H.call("vlg_linear_dgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, pd.data_ptr(), M, N, K,
+               H.EPI_DGELU | S3, stream())
+        uu = pre.double().requires_grad_(True)
+        F.gelu(uu).backward(dref)
+        assert_close(dx, uu.grad.float(), rtol=1e-4, atol=1e-5, what="split dgrad * gelu'")
+    x = torch.randn(M, K)
+    xd = x.to(dev)
+    ns = H.load().vlg_linear_wgrad_slabs_for(M, N, K, S3)
+    stride = N * K + N
+    slabs = torch.full((ns * stride,), float("nan"), device=dev)
+    H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, M, N, K, S3, stream())
+    g = reduce_slabs(H, slabs, stride, ns, stride, dev)
+    sc = math.sqrt(M)
+    assert_close(g[:N * K].view(N, K) / sc, (dy.double().t() @ x.double()).float() / sc, rtol=1e-4, atol=1e-5, what="split wgrad")
+    assert_close(g[N * K:] / sc, dy.double().sum(0).float() / sc, rtol=1e-4, atol=1e-5, what="split bias grad")
+    with pytest.raises(H.HipError):                                  # the split is an fp32-tensor mode
+        H.call("vlg_linear_dgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, 0, M, N, K, S3 | H.EPI_BF16, stream())

@@ -13,10 +13,10 @@ from oracle import layout_spec as O
 pytestmark = pytest.mark.gpu
 
 
-def build(cfg, dev, seed=1024):
+def build(cfg, dev, seed=1024, precision="fp32"):
     from vlg.engine import LayoutEngine
     from vlg.spec import param_shapes
-    eng = LayoutEngine(cfg, dev, seed=seed)
+    eng = LayoutEngine(cfg, dev, seed=seed, precision=precision)
     p = O.init_params(param_shapes(cfg), seed=seed)
     for k, v in eng.named_params().items():          # product init == oracle init, bit for bit
         assert torch.equal(v.cpu(), p[k]), k
@@ -38,10 +38,13 @@ CONFIGS = [
 
 @pytest.mark.parametrize("kw", CONFIGS)
 @pytest.mark.parametrize("variable_n", [False, True])
-def test_step_matches_oracle(dev, kw, variable_n):
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_step_matches_oracle(dev, kw, variable_n, precision):
+    """fp32 = native fp32 MFMA projections; fp32x3 = the same fp32 tensors with every projection computed on the bf16
+    matrix cores from exact three-way operand splits (csrc/gemm_split.hip) - the SAME 1e-4 bar applies to both."""
     from vlg.spec import LayoutConfig
     cfg = LayoutConfig(**kw)
-    eng, p = build(cfg, dev)
+    eng, p = build(cfg, dev, precision=precision)
     batch = O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=7, variable_n=variable_n, min_valid=3)
     parts, grads = O.loss_and_grads(p, batch, cfg.n_layers)
     loss = eng.forward_backward(to_dev(batch, dev))

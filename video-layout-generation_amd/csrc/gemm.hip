@@ -235,6 +235,10 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
 int vlg_gemm16_fwd(GemmArgs g, int epilogue, int io, hipStream_t s);
 int vlg_gemm16_dgrad(GemmArgs g, int epilogue, int io, hipStream_t s);
 int vlg_gemm16_wgrad(GemmArgs g, int io, hipStream_t s);
+// fp32 operands split into three bf16 terms, six bf16 MFMAs per product block (gemm_split.hip)
+int vlg_gemm_split_fwd(GemmArgs g, int epilogue, hipStream_t s);
+int vlg_gemm_split_dgrad(GemmArgs g, int epilogue, hipStream_t s);
+int vlg_gemm_split_wgrad(GemmArgs g, hipStream_t s);
 // storage bits of the epilogue / flags word -> IO template value (bit 0 A, bit 1 B, bit 2 C + aux)
 static int gemm_io_bits(int flags) {
     return ((flags & VLG_EPI_A_BF16) ? 1 : 0) | ((flags & VLG_EPI_B_BF16) ? 2 : 0) | ((flags & VLG_EPI_OUT_BF16) ? 4 : 0);
@@ -253,9 +257,10 @@ extern "C" int vlg_linear_fwd(const void* A, int lda, const void* W, int ldw, co
     g.M = M; g.N = N; g.Kc = K; g.lda = lda; g.ldb = ldw; g.ldc = ldc;
     g.splits = 1; g.kc_per_split = K; g.slab_stride = 0; g.colsum_off = 0;
     hipStream_t s = (hipStream_t)stream;
-    const bool bf16 = (epilogue & VLG_EPI_BF16) != 0;
+    const bool bf16 = (epilogue & VLG_EPI_BF16) != 0, split3 = (epilogue & VLG_EPI_SPLIT3) != 0;
     const int io = gemm_io_bits(epilogue);
-    epilogue &= ~(VLG_EPI_BF16 | VLG_EPI_STORAGE);
+    epilogue &= ~(VLG_EPI_BF16 | VLG_EPI_STORAGE | VLG_EPI_SPLIT3);
+    if (split3 && (bf16 || io != 0)) return VLG_ERR_SHAPE;
     if ((epilogue & VLG_EPI_BIAS) && !bias) return VLG_ERR_SHAPE;
     if ((epilogue & (VLG_EPI_RESID | VLG_EPI_DGELU)) && !aux_in) return VLG_ERR_SHAPE;
     if ((epilogue & VLG_EPI_GELU) && !aux_out) return VLG_ERR_SHAPE;
@@ -263,6 +268,7 @@ extern "C" int vlg_linear_fwd(const void* A, int lda, const void* W, int ldw, co
     if (io != 0 && !bf16) return VLG_ERR_SHAPE;      // bf16 activation storage exists for the bf16 MFMA mode only
     if (((io & 1) && (lda & 7)) || ((io & 2) && (ldw & 7))) return VLG_ERR_ALIGN;
     if (bf16) return vlg_gemm16_fwd(g, epilogue, io, s);
+    if (split3) return vlg_gemm_split_fwd(g, epilogue, s);
     switch (epilogue) {
         case VLG_EPI_BIAS:
             return narrow ? launch_gemm<128, 32, true, true, VLG_EPI_BIAS, false>(g, s)
@@ -286,13 +292,15 @@ extern "C" int vlg_linear_dgrad(const void* dY, int ldy, const void* W, int ldw,
     g.M = M; g.N = K; g.Kc = N; g.lda = ldy; g.ldb = ldw; g.ldc = ldx;
     g.splits = 1; g.kc_per_split = N;
     hipStream_t s = (hipStream_t)stream;
-    const bool bf16 = (epilogue & VLG_EPI_BF16) != 0;
+    const bool bf16 = (epilogue & VLG_EPI_BF16) != 0, split3 = (epilogue & VLG_EPI_SPLIT3) != 0;
     const int io = gemm_io_bits(epilogue);
-    epilogue &= ~(VLG_EPI_BF16 | VLG_EPI_STORAGE);
+    epilogue &= ~(VLG_EPI_BF16 | VLG_EPI_STORAGE | VLG_EPI_SPLIT3);
+    if (split3 && (bf16 || io != 0)) return VLG_ERR_SHAPE;
     if (io != 0 && !bf16) return VLG_ERR_SHAPE;
     if (((io & 1) && (ldy & 7)) || ((io & 2) && (ldw & 7))) return VLG_ERR_ALIGN;
     if (epilogue == VLG_EPI_DGELU && !aux_in) return VLG_ERR_SHAPE;
     if (bf16) return vlg_gemm16_dgrad(g, epilogue, io, s);
+    if (split3) return vlg_gemm_split_dgrad(g, epilogue, s);
     switch (epilogue) {
         case VLG_EPI_NONE:
             return launch_gemm<128, 128, true, false, VLG_EPI_NONE, false>(g, s);
@@ -348,6 +356,7 @@ extern "C" int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
     if (io != 0 && !bf16) return VLG_ERR_SHAPE;
     if (((io & 1) && (ldy & 7)) || ((io & 2) && (ldx & 7))) return VLG_ERR_ALIGN;
     if (bf16) return vlg_gemm16_wgrad(g, io, s);
+    if (flags & VLG_EPI_SPLIT3) return io == 0 ? vlg_gemm_split_wgrad(g, s) : VLG_ERR_SHAPE;
     return N <= 32 ? launch_gemm<32, 128, false, false, VLG_EPI_NONE, true>(g, s)
                    : launch_gemm<128, 128, false, false, VLG_EPI_NONE, true>(g, s);
 }

@@ -65,14 +65,16 @@ class LayoutEngine:
         "bf16"      BASELINE.json configs[2]: bf16 MFMA projections (fp32 accumulate) AND the activations that only
                     feed projections / attention (normalised inputs, q k v, attention output, FFN hidden and their
                     gradients) stored as bf16 in HBM - the mode is HBM-bound, so the bytes are what count;
-        "bf16_mfma" bf16 MFMA projections with every tensor still fp32 in HBM (operands rounded at fragment-read time).
+        "bf16_mfma" bf16 MFMA projections with every tensor still fp32 in HBM (operands rounded on their way to LDS);
+        "fp32x3"    fp32 tensors and fp32-grade projections on the bf16 matrix cores: every operand split exactly into
+                    three bf16 terms, six bf16 MFMAs per product block (csrc/gemm_split.hip).
         The residual stream and its gradient, layer-norm statistics, softmax, losses, weight gradients, Adam and the
         master weights are fp32 in all three."""
         cfg.validate()
-        if precision not in ("fp32", "bf16", "bf16_mfma"):
-            raise ValueError("precision must be fp32, bf16 or bf16_mfma")
+        if precision not in ("fp32", "bf16", "bf16_mfma", "fp32x3"):
+            raise ValueError("precision must be fp32, fp32x3, bf16 or bf16_mfma")
         self.precision = precision
-        self.gemm_flags = 0 if precision == "fp32" else hip.EPI_BF16
+        self.gemm_flags = {"fp32": 0, "fp32x3": hip.EPI_SPLIT3}.get(precision, hip.EPI_BF16)
         self.bf16_store = precision == "bf16"
         self._sfx = "_bf16" if self.bf16_store else ""
         hip.load()                                   # fail loudly before touching the GPU

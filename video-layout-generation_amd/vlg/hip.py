@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvlg_hip.so")
 
 EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_BF16 = 0, 1, 2, 4, 8, 16
-EPI_A_BF16, EPI_B_BF16, EPI_OUT_BF16 = 32, 64, 128      # bf16 activation storage (include/vlg_hip.h)
+EPI_A_BF16, EPI_B_BF16, EPI_OUT_BF16, EPI_SPLIT3 = 32, 64, 128, 256      # bf16 activation storage (include/vlg_hip.h)
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 
