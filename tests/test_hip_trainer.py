@@ -71,3 +71,29 @@ def test_trainer_runs_the_reference_model(tmp_path, monkeypatch):
     again = Trainer(reference_args(tmp_path / "again", resume="../checkpoint/latest.pth", batch_size=2, epochs=1,
                                    print_freq=1, train_clips=8, val_clips=4))
     assert torch.equal(again.engine.engine.net.params, tr.engine.engine.net.params)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32x3", 1e-4), ("bf16", 3e-2)])
+def test_trainer_precision_knob(tmp_path, monkeypatch, precision, tol):
+    """VLG_PRECISION selects the projection mode behind the unchanged Trainer surface: fp32x3 (fp32 tensors, split
+    bf16 MFMAs) must track the oracle-backed Trainer at the fp32 bar; bf16 (bf16 MFMA + bf16 activation storage) at its
+    stated looser one; a checkpoint of the bf16 mode restores the master weights AND the bf16 shadow."""
+    src = tmp_path / "src"
+    src.mkdir()
+    monkeypatch.chdir(src)
+    monkeypatch.setenv("VLG_PRECISION", precision)
+    hip_tr, hip_vals = run(tmp_path, "hip", None)
+    assert hip_tr.engine.precision == precision
+    monkeypatch.delenv("VLG_PRECISION")
+    _, cpu_vals = run(tmp_path, "cpu", oracle_factory)
+    for a, b in zip(hip_vals, cpu_vals):
+        assert abs(a - b) <= tol * abs(b), (hip_vals, cpu_vals)
+    assert hip_vals[1] < hip_vals[0]
+    if precision == "bf16":
+        monkeypatch.setenv("VLG_PRECISION", precision)
+        hip_tr.save_checkpoint({"loss": hip_vals[-1]})
+        from trainer import Trainer
+        again = Trainer(reference_args(tmp_path / "again", resume="../checkpoint/latest.pth", **SMALL))
+        assert torch.equal(again.engine.params, hip_tr.engine.params)
+        assert torch.equal(again.engine.params_bf16, hip_tr.engine.params.to(torch.bfloat16))
+        assert torch.equal(hip_tr.engine.params_bf16, hip_tr.engine.params.to(torch.bfloat16))

@@ -12,7 +12,8 @@ reference's own step is a 2-D CNN that BASELINE.json does not ask for (SURVEY.md
 
 Shape knobs the reference CLI does not have are read with getattr/env defaults so main.py stays
 byte-for-byte unchanged:  VLG_FRAMES (T, 16), VLG_SLOTS (N, 64), VLG_DMODEL (d, 256),
-VLG_LAYERS (4), VLG_TRAIN_CLIPS (1024), VLG_VAL_CLIPS (256), VLG_VARIABLE_N (0).
+VLG_LAYERS (4), VLG_TRAIN_CLIPS (1024), VLG_VAL_CLIPS (256), VLG_VARIABLE_N (0), VLG_PRECISION (fp32 | fp32x3 | bf16 |
+bf16_mfma: projection arithmetic / activation storage, vlg/engine.py).
 
 VLG_MODEL=gridnet switches the step to the reference's OWN model and losses (vlg/image_engine.py:
 --arch GridNet|CoordGridNet on the conv3x3 MFMA kernels, 40 L1 + 20 (GradientLoss + SSIM) + 10 CE, reference
@@ -105,8 +106,10 @@ def get_layout_engine(args, cfg: Optional[LayoutConfig] = None, engine_factory: 
     if engine_factory is None:
         from vlg.engine import LayoutEngine          # HIP only; raises without a GPU / without the .so
         device = torch.device("cuda", int(args.rank))
+        precision = str(getattr(args, "precision", None) or os.environ.get("VLG_PRECISION", "fp32"))
         engine = LayoutEngine(cfg, device, seed=int(getattr(args, "seed", SEED)),
-                              lr=float(getattr(args, "lr", ADAM_LR)), beta1=float(getattr(args, "beta1", ADAM_BETA1)))
+                              lr=float(getattr(args, "lr", ADAM_LR)), beta1=float(getattr(args, "beta1", ADAM_BETA1)),
+                              precision=precision)
     else:
         engine = engine_factory(cfg, args)
     ckpt_path = getattr(args, "ckpt", None)
