@@ -332,9 +332,74 @@ static bool split_96(int64_t rows) { return (rows + 127) / 128 < 400; }
 
 static bool conv_ok(const void* p) { return p != nullptr && vlg_aligned16(p); }
 
+// Split-K forward for the coarse levels of the VGG / HED trunks (4 x 32 x 32 or 16 x 16 pixels, 256-512 channels): the
+// plain launch has 44-148 blocks for 256 CUs while K = 9*cin is 2304-4608, so the contraction is cut into `splits`
+// ranges, every range writes a raw partial tile to the caller's workspace and conv_finish_kernel sums them and applies
+// the epilogue (bias, residual, row mask).  Partial sums are added in a fixed order: reproducible.
+static int conv_fwd_splits(int64_t rows_out, int cin_p, int cout, int cout_p) {
+    if (cout_p < 128 || cout != cout_p || cin_p < 128) return 1;
+    const int64_t b128 = ((rows_out + 127) / 128) * ((cout_p + 127) / 128);
+    if (b128 >= 200) return 1;                                 // (splitting 200-400 block launches in two was measured: no gain)
+    int s = (int)(512 / b128);
+    if (s > 8) s = 8;
+    const int ktiles = 9 * cin_p / 32;
+    while (s > 1 && ktiles / s < 8) --s;                       // keep at least 8 K tiles per block
+    return s < 2 ? 1 : s;
+}
+extern "C" int vlg_conv3x3_fwd_splits(int64_t rows_out, int cin_p, int cout, int cout_p) {
+    return conv_fwd_splits(rows_out, cin_p, cout, cout_p);
+}
+
+__global__ __launch_bounds__(256) void conv_finish_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride,
+                                                          const float* __restrict__ bias, const float* __restrict__ resid,
+                                                          const float* __restrict__ rowmask, float* __restrict__ out,
+                                                          int64_t rows, int cq /* float4 per row */) {
+    const int64_t n4 = rows * cq;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / cq;
+        const int c4 = (int)(e - row * cq);
+        float4 acc = ld4(slabs + e * 4);
+        for (int s = 1; s < splits; ++s) acc = f4_add(acc, ld4(slabs + s * slab_stride + e * 4));
+        if (bias != nullptr) acc = f4_add(acc, ld4(bias + c4 * 4));
+        if (resid != nullptr) acc = f4_add(acc, ld4(resid + e * 4));
+        if (rowmask != nullptr) { const float m = rowmask[row]; acc = make_float4(acc.x * m, acc.y * m, acc.z * m, acc.w * m); }
+        st4(out + e * 4, acc);
+    }
+}
+
+// data-gradient counterpart: din = mask * sum (zeroed on the constant AddCoords channels) * act'(x_in) (+ din)
+__global__ __launch_bounds__(256) void conv_finish_dgrad_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride,
+                                                                const float* __restrict__ x_in, const float* __restrict__ rowmask,
+                                                                float slope_is_valid, const float* __restrict__ slope_p,
+                                                                float* __restrict__ din, int64_t rows, int cq, int act_ch, int epi) {
+    const int64_t n4 = rows * cq;
+    const float slope = slope_is_valid != 0.f ? slope_p[0] : 1.0f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / cq;
+        const int c = (int)(e - row * cq) * 4;
+        float4 acc = ld4(slabs + e * 4);
+        for (int s = 1; s < splits; ++s) acc = f4_add(acc, ld4(slabs + s * slab_stride + e * 4));
+        float v[4] = {acc.x, acc.y, acc.z, acc.w};
+        const float m = rowmask != nullptr ? rowmask[row] : 1.0f;
+        float4 x = f4_zero();
+        if (epi & VLG_CEPI_DPRELU) x = ld4(x_in + e * 4);
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] *= m;
+            if (c + k >= act_ch) v[k] = 0.f;
+            else if ((epi & VLG_CEPI_DPRELU) && !(xv[k] > 0.f)) v[k] *= slope;
+        }
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (epi & VLG_CEPI_ACCUM) o = f4_add(o, ld4(din + e * 4));
+        st4(din + e * 4, o);
+    }
+}
+
 extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bias, float* out, const float* resid,
                                const float* rowmask, const float* prelu_slope, const int* rowtab, int64_t rows_out,
-                               int cin_p, int cout, int cout_p, int wp_in, int act_ch, int epilogue, void* stream) {
+                               int cin_p, int cout, int cout_p, int wp_in, int act_ch, int epilogue, float* workspace,
+                               void* stream) {
     if (rows_out < 1 || cin_p < 32 || (cin_p & 31) || cout < 1 || cout > cout_p || (cout_p & 31)) return VLG_ERR_SHAPE;
     if (!conv_ok(in) || !conv_ok(w) || !conv_ok(out)) return VLG_ERR_ALIGN;
     if ((epilogue & VLG_CEPI_RESID) && !resid) return VLG_ERR_SHAPE;
@@ -346,6 +411,22 @@ extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bia
     g.splits = 1; g.kc_per_split = g.Kc; g.epi = epilogue & ~VLG_CEPI_DPRELU; g.act_ch = act_ch;
     fill_shifts(g, wp_in, rowtab ? 1 : 1);
     hipStream_t s = (hipStream_t)stream;
+    const int splits = workspace != nullptr ? conv_fwd_splits(rows_out, cin_p, cout, cout_p) : 1;
+    if (splits > 1) {
+        if (!vlg_aligned16(workspace) || (epilogue & VLG_CEPI_PRELU)) return VLG_ERR_ALIGN;
+        const int ktiles = 9 * cin_p / 32;
+        g.splits = splits;
+        g.kc_per_split = (int64_t)((ktiles + splits - 1) / splits) * 32;
+        g.slab_stride = rows_out * (int64_t)cout_p;
+        g.C = workspace; g.bias = nullptr; g.aux_in = nullptr; g.rowmask = nullptr; g.epi = 0;    // raw partial tiles
+        if (int e = launch_conv<CONV_FWD, 128, 128>(g, s)) return e;
+        const int64_t n4 = rows_out * (cout_p / 4);
+        int64_t blocks = (n4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, splits, g.slab_stride, bias,
+                           (epilogue & VLG_CEPI_RESID) ? resid : nullptr, rowmask, out, rows_out, cout_p / 4);
+        return vlg_last_error();
+    }
     if (cout_p == 32) return conv_narrow_bk() == 16 ? launch_conv<CONV_FWD, 128, 32, 16>(g, s) : launch_conv<CONV_FWD, 128, 32>(g, s);
     if (cout_p == 96) return split_96(rows_out) ? launch_conv<CONV_FWD, 128, 32>(g, s) : launch_conv<CONV_FWD, 128, 96>(g, s);
     // small grids (coarse levels, small batches) would leave CUs idle with 128-row tiles: halve the tile height
@@ -363,10 +444,14 @@ extern "C" int vlg_conv3x3_dgrad_slabs(int64_t rows_in, int cin_p) {
     return (int)((rows_in + bm - 1) / bm) * tiles_n;
 }
 
+// K ranges of the data gradient when given a workspace: frozen trunks only (no slope gradient wanted), stride 1
+static int conv_dgrad_splits(int64_t rows_in, int cin_p, int cout_p) { return conv_fwd_splits(rows_in, cout_p, cin_p, cin_p); }
+extern "C" int vlg_conv3x3_dgrad_splits(int64_t rows_in, int cin_p, int cout_p) { return conv_dgrad_splits(rows_in, cin_p, cout_p); }
+
 extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, const float* x_in,
                                  const float* rowmask_in, const float* prelu_slope, float* da_slab,
                                  const int* tap_tables, int64_t tab_stride, int64_t rows_in, int cin_p, int cout_p,
-                                 int wp, int act_ch, int epilogue, void* stream) {
+                                 int wp, int act_ch, int epilogue, float* workspace, void* stream) {
     // din[p, ci] = mask[p] * sum_tap sum_co dout[p - shift(tap), co] * W[co][tap][ci]   (stride 1)
     // stride 2: tap_tables[tap][p] = output row feeding input row p through that tap (or a zero guard row)
     if (rows_in < 1 || cin_p < 32 || (cin_p & 31) || (cin_p > 128 && (cin_p & 127)) || cout_p < 32 || (cout_p & 31))
@@ -382,6 +467,24 @@ extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, 
     if (tap_tables) { for (int t = 0; t < 9; ++t) g.shift[t] = 0; }
     else fill_shifts(g, wp, -1);
     hipStream_t s = (hipStream_t)stream;
+    const int splits = (workspace != nullptr && da_slab == nullptr && tap_tables == nullptr) ? conv_dgrad_splits(rows_in, cin_p, cout_p) : 1;
+    if (splits > 1) {
+        if (!vlg_aligned16(workspace)) return VLG_ERR_ALIGN;
+        const int ktiles = 9 * cout_p / 32;
+        g.splits = splits;
+        g.kc_per_split = (int64_t)((ktiles + splits - 1) / splits) * 32;
+        g.slab_stride = rows_in * (int64_t)cin_p;
+        g.C = workspace; g.rowmask = nullptr; g.epi = 0; g.aux_in = nullptr;       // raw partial tiles
+        g.act_ch = cin_p;                                                          // (the finish kernel cuts the constant channels)
+        if (int e = launch_conv<CONV_DGRAD, 128, 128>(g, s)) return e;
+        const int64_t n4 = rows_in * (cin_p / 4);
+        int64_t blocks = (n4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(conv_finish_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, splits, g.slab_stride, x_in,
+                           rowmask_in, prelu_slope ? 1.0f : 0.0f, prelu_slope, din, rows_in, cin_p / 4, act_ch,
+                           epilogue & (VLG_CEPI_DPRELU | VLG_CEPI_ACCUM));
+        return vlg_last_error();
+    }
     if (cin_p == 32) return conv_narrow_bk() == 16 ? launch_conv<CONV_DGRAD, 128, 32, 16>(g, s) : launch_conv<CONV_DGRAD, 128, 32>(g, s);
     if (cin_p == 96) return split_96(rows_in) ? launch_conv<CONV_DGRAD, 128, 32>(g, s) : launch_conv<CONV_DGRAD, 128, 96>(g, s);
     const bool small = few_blocks(rows_in, cin_p == 64 ? 1 : (cin_p + 127) / 128);
