@@ -90,6 +90,10 @@ def load() -> ctypes.CDLL:
         raise HipError(
             "libvlg_hip.so not found at %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C video-layout-generation_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64.so; it must be in the process BEFORE libvlg_hip.so is dlopen'ed so that both
+    # bind to ONE HIP runtime (torch streams and device pointers are handed to the kernels).  Loaded the other way
+    # round the library pulls /opt/rocm's runtime first and every launch fails with hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
