@@ -90,8 +90,9 @@ int vlg_layernorm_bwd_bf16(const vlg_bf16* dy, const float* x, const float* mean
 #define VLG_EPI_GELU   2   /* aux_out = pre-activation, C = gelu(pre)   (needs BIAS) */
 #define VLG_EPI_RESID  4   /* C = acc (+bias) + aux_in[row,col]                      */
 #define VLG_EPI_DGELU  8   /* C = acc * gelu'(aux_in[row,col])                       */
-#define VLG_EPI_BF16   16  /* operands rounded to bf16 for v_mfma_f32_32x32x16_bf16, fp32 accumulate and fp32
-                              tensors in HBM (BASELINE.json configs[2]); default is exact-fp32 MFMA  */
+#define VLG_EPI_BF16   16  /* v_mfma_f32_32x32x16_bf16 with fp32 accumulate (BASELINE.json configs[2]); fp32 operands are rounded
+                              to bf16 on their way to LDS, bf16 ones (storage bits below) are copied; default is native
+                              fp32 MFMA */
 #define VLG_EPI_SPLIT3 256  /* fp32 tensors, fp32-grade result on the bf16 matrix cores: each operand is split exactly into
                               three bf16 terms and a product block is six v_mfma_f32_32x32x16_bf16 (a1b1 + a1b2 + a2b1 +
                               a1b3 + a2b2 + a3b1, fp32 accumulate; the dropped terms are <= 3 * 2^-24 |a||b|)          */

@@ -129,8 +129,8 @@ def test_full_size_properties(dev, shape):
 @pytest.mark.parametrize("precision,T", [("bf16", 16), ("bf16_mfma", 16), ("bf16", 8)])
 def test_bf16_projection_mode(dev, precision, T):
     """BASELINE.json configs[2]: the same step with bf16 MFMA projections (fp32 accumulate), either with the
-    projection-side activations stored as bf16 in HBM ("bf16") or with fp32 tensors and operands rounded at
-    fragment-read time ("bf16_mfma").  bf16 has 8 significand bits, so this is NOT a 1e-4 parity mode: the loss
+    projection-side activations stored as bf16 in HBM ("bf16") or with fp32 tensors and operands rounded on their
+    way to LDS ("bf16_mfma").  bf16 has 8 significand bits, so this is NOT a 1e-4 parity mode: the loss
     must agree with the fp32 oracle to 2e-2 relative and every gradient tensor to 5e-2 in relative L2 (stated
     tolerance), and training must still make progress."""
     from vlg.engine import LayoutEngine
