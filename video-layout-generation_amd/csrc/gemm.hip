@@ -122,18 +122,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
             TB::template gload<GUARD>(xb, gB, g.ldb, n0, g.N, k0, kend, tid);
         };
         auto iter = [&](int kt, float4 (&xa)[TA::NV], float4 (&xb)[TB::NV]) {
-            // Two blocks share every SIMD and the issue arbiter favours the OLDER wave, so the block dispatched first ran
-            // ahead and the other finished alone, one wave per SIMD, at poor MFMA utilisation (per-block loop times spread
-            // 120-160 us in the weight gradient; measured gain of this: ~2 % on that kernel).  Priority that falls with progress lets whichever block is behind catch
-            // up: the pair stays within a quarter of the loop of each other and finishes together.
-            if ((kt & 3) == 0) {
-                switch ((4 * kt) / nk) {
-                    case 0: __builtin_amdgcn_s_setprio(3); break;
-                    case 1: __builtin_amdgcn_s_setprio(2); break;
-                    case 2: __builtin_amdgcn_s_setprio(1); break;
-                    default: __builtin_amdgcn_s_setprio(0); break;
-                }
-            }
             const int cur = kt & 1;
             const float* as = As0 + cur * TA::FLOATS;
             const float* bs = Bs0 + cur * TB::FLOATS;
