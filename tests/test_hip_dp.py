@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 CFG = dict(B=2, T=8, N=8, d=64, n_layers=2)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, precision="fp32"):
     for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -28,7 +28,7 @@ def _worker(rank, world, port, out):
     from vlg.spec import LayoutConfig
     dev = torch.device("cuda:0")
     cfg = LayoutConfig(**CFG)
-    eng = LayoutEngine(cfg, dev, seed=1024)
+    eng = LayoutEngine(cfg, dev, seed=1024, precision=precision)
     red = GradReducer(eng.grads_ext, bucket_ranges(eng.layout, eng.n_params, cfg.n_layers))
     losses = []
     for step in range(2):
@@ -38,7 +38,8 @@ def _worker(rank, world, port, out):
         losses.append(float(loss[0]) / world)
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({"params": eng.params.cpu(), "losses": losses}, out)
+        shadow_ok = eng.params_bf16 is None or bool(torch.equal(eng.params_bf16, eng.params.to(torch.bfloat16)))
+        torch.save({"params": eng.params.cpu(), "losses": losses, "shadow_ok": shadow_ok}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,3 +67,25 @@ def test_two_processes_match_one_big_batch(dev, tmp_path):
     # elements with a real gradient agree; zero-gradient ones (key bias) get +-lr of rounding noise from Adam
     assert torch.allclose(got["params"][signal], p[signal], rtol=1e-4, atol=1e-6)
     assert float((got["params"] - p).abs().max()) <= 2 * 2 * ADAM_LR * 1.01
+
+
+def test_two_processes_bf16_mode(dev, tmp_path):
+    """The bf16 mode under data parallelism: the Adam of the split-range path (everything but the embeddings first, the
+    embedding range after its bucket arrives) must keep the bf16 weight shadow equal to the rounded master weights, and
+    the step must track the single-process bf16 step on the union batch at the mode's tolerance."""
+    world, out = 2, str(tmp_path / "dp16.pt")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, out, "bf16"), nprocs=world, join=True)
+    got = torch.load(out, weights_only=True)
+    assert got["shadow_ok"]
+    from oracle import layout_spec as O
+    from vlg.engine import LayoutEngine
+    from vlg.spec import LayoutConfig
+    cfg = LayoutConfig(**dict(CFG, B=CFG["B"] * world))
+    eng = LayoutEngine(cfg, dev, seed=1024, precision="bf16")
+    for step in range(2):
+        full = O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=60 + step)
+        loss = float(eng.train_step({k: v.to(dev) for k, v in full.items()})[0])
+        assert abs(got["losses"][step] - loss) <= 2e-2 * abs(loss), (got["losses"], loss)
