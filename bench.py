@@ -109,13 +109,19 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path for the product")
+    if os.environ.get("VLG_BENCH_ONE_DEVICE", "0") == "1":
+        local = 0                                    # rehearsal: every rank on the one GPU of a test box (with gloo, below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     distributed = world > 1 or "RANK" in os.environ          # under torch.distributed.run even at N=1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=dev)   # nccl == RCCL on ROCm
+        backend = os.environ.get("VLG_BENCH_BACKEND", "nccl")                       # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=dev)
+        else:                                        # rehearsal of the multi-rank control flow on one GPU (RCCL refuses that)
+            dist.init_process_group(backend=backend, world_size=world, rank=rank)
 
     from vlg.data import synthetic_clips, to_device
     from vlg.dp import GradReducer, bucket_ranges
@@ -180,9 +186,10 @@ def main():
             fam = DOMINANT
             s = summ[fam]
             # untimed diagnostic pass: every GEMM family bracketed, to show the dominant one IS dominant
+            # (rank 0 only, so WITHOUT the reducer: a collective here would have no partner on the other ranks)
             eng.timer = KernelTimer()
             for _ in range(2):
-                eng.train_step(batch, reducer)
+                eng.train_step(batch, None)
             torch.cuda.synchronize()
             allf = eng.timer.summary()
             achieved = s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
