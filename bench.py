@@ -143,6 +143,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if reducer is not None:
+        # communicator set-up (RCCL builds its rings on the first collective) is not part of a step: do it now
+        dist.all_reduce(torch.zeros(4, device=dev))
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         eng.train_step(batch, reducer)
     # Inside the timed region only the dominant kernel (the weight-gradient GEMM instantiation: top of
