@@ -144,6 +144,13 @@ int vlg_layout_loss(const float* out, int ld, const int64_t* tgt_class, const fl
 int vlg_reduce_slabs(const float* slabs, int64_t slab_stride, int n_slabs,
                      float* dst, int64_t len, void* stream);
 
+/* Many reductions in one launch, driven by a DEVICE table (static graphs: the reference GridNet's 61 convolutions).
+ * vlg_reduce_slabs_table: row i = {slabs pointer, slab stride, slab count, destination pointer, length} (int64 each);
+ * every row is reduced exactly as vlg_reduce_slabs would.  vlg_sum_partials_table: row i = {partials pointer, count,
+ * destination pointer}: dst[0] = sum (vlg_sum_partials with accumulate = 0). */
+int vlg_reduce_slabs_table(const int64_t* table, int n_rows, int blocks_per_row, void* stream);
+int vlg_sum_partials_table(const int64_t* table, int n_rows, void* stream);
+
 /* ------------------------------------------------------------------- optimiser
  * torch.optim.Adam(lr, betas=(beta1, 0.999)) on one flat fp32 buffer
  * (reference src/trainer.py:83,258; src/main.py:139-141).  `step` is 1-based.

@@ -87,6 +87,84 @@ static unsigned stream_blocks(int64_t n4) {
     return (unsigned)b;
 }
 
+// Many independent reductions in ONE launch (blockIdx.y = table row): the backward of the reference's GridNet leaves one
+// slab set per convolution (61) - each a few microseconds of work behind its own launch.  table[i] = {slabs pointer,
+// slab stride, slab count, destination pointer, length}, int64 each, in DEVICE memory (built once: the tape is static).
+// Every row is reduced exactly as vlg_reduce_slabs would reduce it (same summation order).
+__global__ __launch_bounds__(256) void reduce_slabs_table_kernel(const int64_t* __restrict__ table) {
+    __shared__ float4 part[16][16];
+    const int64_t* t = table + 5 * (int64_t)blockIdx.y;
+    const float* __restrict__ slabs = reinterpret_cast<const float*>(t[0]);
+    const int64_t stride = t[1];
+    const int n_slabs = (int)t[2];
+    float* __restrict__ dst = reinterpret_cast<float*>(t[3]);
+    const int64_t len4 = t[4] / 4;
+    if (len4 < 32768 && n_slabs >= 16) {                       // as reduce_slabs_tall_kernel
+        const int c = threadIdx.x & 15, sg = threadIdx.x >> 4;
+        for (int64_t blk = blockIdx.x; blk * 16 < len4; blk += gridDim.x) {
+            const int64_t col = blk * 16 + c;
+            float4 acc = f4_zero();
+            if (col < len4) {
+                const float* p = slabs + col * 4;
+                int s = sg;
+                for (; s + 48 < n_slabs; s += 64) {
+                    const float4 a = ld4(p + s * stride), b2 = ld4(p + (s + 16) * stride);
+                    const float4 c2 = ld4(p + (s + 32) * stride), d = ld4(p + (s + 48) * stride);
+                    acc = f4_add(acc, f4_add(f4_add(a, b2), f4_add(c2, d)));
+                }
+                for (; s < n_slabs; s += 16) acc = f4_add(acc, ld4(p + s * stride));
+            }
+            part[sg][c] = acc;
+            __syncthreads();
+            if (sg == 0 && col < len4) {
+                float4 v = part[0][c];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) v = f4_add(v, part[k][c]);
+                st4(dst + col * 4, v);
+            }
+            __syncthreads();
+        }
+    } else {                                                   // as reduce_slabs_kernel
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len4; e += (int64_t)gridDim.x * blockDim.x) {
+            float4 acc = f4_zero();
+            const float* p = slabs + e * 4;
+            int s = 0;
+            for (; s + 4 <= n_slabs; s += 4) {
+                const float4 a = ld4(p), b2 = ld4(p + stride), c = ld4(p + 2 * stride), d = ld4(p + 3 * stride);
+                acc = f4_add(acc, f4_add(f4_add(a, b2), f4_add(c, d)));
+                p += 4 * stride;
+            }
+            for (; s < n_slabs; ++s) { acc = f4_add(acc, ld4(p)); p += stride; }
+            st4(dst + e * 4, acc);
+        }
+    }
+}
+
+extern "C" int vlg_reduce_slabs_table(const int64_t* table, int n_rows, int blocks_per_row, void* stream) {
+    if (!table || n_rows < 1 || n_rows > 65535 || blocks_per_row < 1 || blocks_per_row > 4096) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL(reduce_slabs_table_kernel, dim3((unsigned)blocks_per_row, (unsigned)n_rows), dim3(256), 0,
+                       (hipStream_t)stream, table);
+    return vlg_last_error();
+}
+
+// table[i] = {partials pointer, count, destination pointer}: dst[0] = sum of the partials (as vlg_sum_partials, accumulate = 0)
+__global__ __launch_bounds__(256) void sum_partials_table_kernel(const int64_t* __restrict__ table) {
+    __shared__ float red[4];
+    const int64_t* t = table + 3 * (int64_t)blockIdx.x;
+    const float* __restrict__ part = reinterpret_cast<const float*>(t[0]);
+    const int n = (int)t[1];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) reinterpret_cast<float*>(t[2])[0] = s;
+}
+
+extern "C" int vlg_sum_partials_table(const int64_t* table, int n_rows, void* stream) {
+    if (!table || n_rows < 1) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL(sum_partials_table_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, table);
+    return vlg_last_error();
+}
+
 extern "C" int vlg_reduce_slabs(const float* slabs, int64_t slab_stride, int n_slabs, float* dst, int64_t len,
                                 void* stream) {
     if (n_slabs < 1 || len < 4 || (len & 3) || (slab_stride & 3) || slab_stride < len) return VLG_ERR_SHAPE;

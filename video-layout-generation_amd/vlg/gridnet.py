@@ -135,11 +135,29 @@ class GridNetHIP:
         self.img = self._block("lateral_out_img", "lateral", x0, img_out)
         self._alloc_params()
         lib = hip.load()
+        # Backward scratch: every convolution owns a region of the slab arena (weight-gradient partials) and, if a PReLU
+        # precedes it, of the slope-gradient arena; two table-driven launches at the end of backward() reduce them all
+        # (vlg_reduce_slabs_table / vlg_sum_partials_table) instead of two tiny launches per convolution.
         convs = [op for op in self.tape if isinstance(op, _Conv)]
-        slab = max(lib.vlg_conv3x3_wgrad_slabs(c.out.geo.rows, c.x.cp, c.out.cp) * (c.out.cp * 9 * c.x.cp + c.out.cp) for c in convs)
-        self.slabs = torch.empty(slab, dtype=torch.float32, device=device)
-        self.da_part = torch.zeros(max(lib.vlg_conv3x3_dgrad_slabs(c.x.geo.rows, c.x.cp) for c in convs) + 8,
-                                   dtype=torch.float32, device=device)
+        off = da_off = 0
+        for c in convs:
+            c.n_slabs = lib.vlg_conv3x3_wgrad_slabs(c.out.geo.rows, c.x.cp, c.out.cp)
+            c.slab_stride = c.out.cp * 9 * c.x.cp + c.out.cp
+            c.slab_off = off
+            off += (c.n_slabs * c.slab_stride + 3) // 4 * 4
+            c.da_n = lib.vlg_conv3x3_dgrad_slabs(c.x.geo.rows, c.x.cp) if c.prelu else 0
+            c.da_off = da_off
+            da_off += (c.da_n + 3) // 4 * 4
+        self.slabs = torch.empty(off, dtype=torch.float32, device=device)
+        self.da_part = torch.zeros(da_off + 8, dtype=torch.float32, device=device)
+        rows = [[self.slabs.data_ptr() + 4 * c.slab_off, c.slab_stride, c.n_slabs, self.grads.data_ptr() + 4 * c.w_off,
+                 c.slab_stride] for c in convs]
+        self.reduce_table = torch.tensor(rows, dtype=torch.int64).to(device)
+        drows = [[self.da_part.data_ptr() + 4 * c.da_off, c.da_n, self.grads.data_ptr() + 4 * self.p_off[c.prelu]]
+                 for c in convs if c.prelu]
+        self.da_table = torch.tensor(drows, dtype=torch.int64).to(device) if drows else None
+        self.n_da = len(drows)
+        self.n_convs = len(convs)
 
     # ------------------------------------------------------------------ graph construction
     def _tensor(self, level: int, C: int, coord: bool = False) -> _PT:
@@ -295,24 +313,17 @@ class GridNetHIP:
                     raise RuntimeError("no gradient reached the output of %s" % op.key)
                 slope = self._pp(self.p_off[op.prelu]) if op.prelu else 0
                 # weight + bias gradient
-                stride_len = op.out.cp * 9 * op.x.cp + op.out.cp
-                n_slabs = lib.vlg_conv3x3_wgrad_slabs(go.rows, op.x.cp, op.out.cp)
-                call("vlg_conv3x3_wgrad", dout.ptr, op.x.ptr, ptr(self.slabs), stride_len,
+                call("vlg_conv3x3_wgrad", dout.ptr, op.x.ptr, self.slabs.data_ptr() + 4 * op.slab_off, op.slab_stride,
                      ptr(gx.down_rowtab) if op.stride == 2 else 0, slope, go.rows, op.x.cp, op.out.cp, gx.wp, op.act_ch, s)
-                call("vlg_reduce_slabs", ptr(self.slabs), stride_len, n_slabs, self.grads.data_ptr() + 4 * op.w_off,
-                     stride_len, s)
                 # data gradient (skipped for the network input unless asked for)
                 if op.x is not self.x or self.need_input_grad or op.prelu:
                     gin = self._grad_of(op.x)
                     epi = (CEPI_ACCUM if op.x.grad_written else 0) | (CEPI_DPRELU if op.prelu else 0)
                     taps = ptr(gx.down_taptabs) if op.stride == 2 else 0
                     call("vlg_conv3x3_dgrad", dout.ptr, self._pp(op.w_off), gin.ptr, op.x.ptr, ptr(gx.mask), slope,
-                         ptr(self.da_part) if op.prelu else 0, taps, gx.rows if op.stride == 2 else 0, gx.rows, op.x.cp,
+                         self.da_part.data_ptr() + 4 * op.da_off if op.prelu else 0, taps, gx.rows if op.stride == 2 else 0, gx.rows, op.x.cp,
                          op.out.cp, gx.wp, op.act_ch, epi, 0, s)
                     op.x.grad_written = True
-                    if op.prelu:
-                        nb = lib.vlg_conv3x3_dgrad_slabs(gx.rows, op.x.cp)
-                        call("vlg_sum_partials", ptr(self.da_part), nb, self.grads.data_ptr() + 4 * self.p_off[op.prelu], 0, s)
                 # the other branch of the residual sum receives the same gradient (gridnet.py:51-56)
                 if op.resid is not None:
                     gr = self._grad_of(op.resid)
@@ -324,6 +335,10 @@ class GridNetHIP:
                 call("vlg_upsample2x_bwd", dst.grad.ptr, gs.ptr, src.geo.b, src.geo.H, src.geo.W, src.cp,
                      1 if src.grad_written else 0, s)
                 src.grad_written = True
+        # every weight / bias gradient and every PReLU slope gradient, two launches
+        call("vlg_reduce_slabs_table", ptr(self.reduce_table), self.n_convs, 64, s)
+        if self.da_table is not None:
+            call("vlg_sum_partials_table", ptr(self.da_table), self.n_da, s)
         if self.need_input_grad:
             dx = torch.empty(g0.b, self.n_channels, g0.H, g0.W, dtype=torch.float32, device=self.device)
             call("vlg_padded_to_nchw", self.x.grad.ptr, ptr(dx), g0.b, self.n_channels, g0.H, g0.W, self.x.cp, s)

@@ -43,6 +43,8 @@ SIGNATURES = {
     "vlg_layout_loss_scratch": (I, []),
     "vlg_layout_loss": (I, [P, I, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, P]),
     "vlg_reduce_slabs": (I, [P, L, I, P, L, P]),
+    "vlg_reduce_slabs_table": (I, [P, I, I, P]),
+    "vlg_sum_partials_table": (I, [P, I, P]),
     "vlg_adam_step": (I, [P, P, P, P, L, I, F, F, F, F, F, P]),
     "vlg_adam_step_bf16": (I, [P, P, P, P, P, L, I, F, F, F, F, F, P]),
     "vlg_image_loss_scratch": (I, []),
