@@ -60,7 +60,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     constexpr int KPR = BK / 4;                            // float4 per K-contiguous tile row
     constexpr bool A_KC = MODE != CONV_WGRAD;
     constexpr bool B_KC = MODE == CONV_FWD;
-    constexpr int WM = (BM == 32) ? 1 : (BM == 64 ? 2 : ((BN == 128 || BN == 64) ? 2 : 4));
+    // weight gradient: the four waves split the 128 columns, each takes every row tile (BM = Cout = 32, 64 or 96)
+    constexpr int WM = MODE == CONV_WGRAD ? 1 : (BM == 32) ? 1 : (BM == 64 ? 2 : ((BN == 128 || BN == 64) ? 2 : 4));
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     static_assert(TM >= 1 && TN >= 1 && TM * 32 * WM == BM && TN * 32 * WN == BN, "tile / wave layout");
@@ -492,8 +493,15 @@ extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, 
     return small ? launch_conv<CONV_DGRAD, 64, 128>(g, s) : launch_conv<CONV_DGRAD, 128, 128>(g, s);
 }
 
+// row-tile height of the weight gradient: all of Cout for the GridNet widths (one pass over the gathered activation
+// tile serves every output channel), 32-row tiles otherwise.  VLG_CONV_WGRAD_TALL=0 forces 32 (development switch).
+static int conv_wgrad_bm(int cout_p) {
+    static int tall = -1;
+    if (tall < 0) { const char* e = getenv("VLG_CONV_WGRAD_TALL"); tall = e ? atoi(e) : 1; }
+    return (tall && (cout_p == 64 || cout_p == 96)) ? cout_p : 32;
+}
 static void conv_wgrad_plan(int64_t rows, int cin_p, int cout_p, int* splits, int64_t* per) {
-    const int64_t tiles = (cout_p / 32) * (int64_t)((9 * cin_p + 127) / 128);
+    const int64_t tiles = (cout_p / conv_wgrad_bm(cout_p)) * (int64_t)((9 * cin_p + 127) / 128);
     int64_t want = 512 / tiles;
     const int64_t max_splits = (rows + 255) / 256;
     if (want > max_splits) want = max_splits;
@@ -526,5 +534,9 @@ extern "C" int vlg_conv3x3_wgrad(const float* dout, const float* in, float* slab
     conv_wgrad_plan(rows, cin_p, cout_p, &g.splits, &g.kc_per_split);
     g.slab_stride = slab_stride; g.colsum_off = (int64_t)cout_p * 9 * cin_p; g.act_ch = act_ch;
     fill_shifts(g, wp_in, 1);
-    return launch_conv<CONV_WGRAD, 32, 128>(g, (hipStream_t)stream);
+    switch (conv_wgrad_bm(cout_p)) {
+        case 64: return launch_conv<CONV_WGRAD, 64, 128>(g, (hipStream_t)stream);
+        case 96: return launch_conv<CONV_WGRAD, 96, 128>(g, (hipStream_t)stream);
+        default: return launch_conv<CONV_WGRAD, 32, 128>(g, (hipStream_t)stream);
+    }
 }
