@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f32x3", "bf16"], default="f32",
                     help="f32 (default): native fp32 MFMA projections, parity 1e-4; f32x3: fp32 tensors, projections on the "
                          "bf16 matrix cores from exact 3-way operand splits (same 1e-4 parity); bf16: BASELINE configs[2] mode")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from one captured hipGraph (single GPU; same kernels, one host call per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -147,21 +149,27 @@ def main():
         # communicator set-up (RCCL builds its rings on the first collective) is not part of a step: do it now
         dist.all_reduce(torch.zeros(4, device=dev))
         torch.cuda.synchronize()
+    step_fn = lambda: eng.train_step(batch, reducer)
+    if args.graph:
+        if reducer is not None:
+            raise SystemExit("--graph captures the single-process step; the data-parallel hooks are not captured")
+        captured = eng.capture_train_step(batch)
+        step_fn = lambda: captured(batch)
     for _ in range(args.warmup):
-        eng.train_step(batch, reducer)
+        step_fn()
     if args.warmup == 0:
         # code objects are loaded on a kernel's first launch (tens of ms): with --warmup 0 run one untimed step anyway, so
         # the K timed steps measure the step and not the loader (reported as "primed": true)
-        eng.train_step(batch, reducer)
+        step_fn()
     # Inside the timed region only the dominant kernel (the weight-gradient GEMM instantiation: top of
     # every rocprof summary in profiles/) is bracketed with events, and only on every 4th step (16 launches each):
     # an event pair around each of its launches costs ~2 % of `value`, around all ~70 GEMM launches far more.
-    ktimer = None if args.no_kernel_timing else KernelTimer(only=(DOMINANT,))
+    ktimer = None if (args.no_kernel_timing or args.graph) else KernelTimer(only=(DOMINANT,))   # events are not part of a replayed graph
     sync_all()
     t0 = time.perf_counter()
     for it in range(args.steps):
         eng.timer = ktimer if it % 4 == 0 else None
-        eng.train_step(batch, reducer)
+        step_fn()
     eng.timer = ktimer
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -179,7 +187,7 @@ def main():
             "value": round(clips / elapsed, 2), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "primed": args.warmup == 0, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic", "hipgraph": bool(args.graph),
             "config": {"workload": "layout-token training step, (B,T,N)=(%d,%d,%d) clips per GPU, d=%d"
                                    % (cfg.B, cfg.T, cfg.N, cfg.d),
                        "global_batch": world * cfg.B, "parallelism": "dp%d" % world,

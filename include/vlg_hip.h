@@ -144,6 +144,14 @@ int vlg_layout_loss(const float* out, int ld, const int64_t* tgt_class, const fl
 int vlg_reduce_slabs(const float* slabs, int64_t slab_stride, int n_slabs,
                      float* dst, int64_t len, void* stream);
 
+/* Adam whose step counter lives on the device, for a step captured in a hipGraph (a replayed launch cannot take new
+ * by-value arguments): state = {float step_size, float sqrt_bc2, int step, int pad}, 16-byte aligned; the call advances
+ * the counter (advance != 0), recomputes the two bias-correction factors in double as vlg_adam_step does on the host,
+ * then updates.  shadow may be NULL. */
+int vlg_adam_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, vlg_bf16* shadow,
+                        int64_t n, float* state, int advance, float lr, float beta1, float beta2, float eps,
+                        float grad_scale, void* stream);
+
 /* Many reductions in one launch, driven by a DEVICE table (static graphs: the reference GridNet's 61 convolutions).
  * vlg_reduce_slabs_table: row i = {slabs pointer, slab stride, slab count, destination pointer, length} (int64 each);
  * every row is reduced exactly as vlg_reduce_slabs would.  vlg_sum_partials_table: row i = {partials pointer, count,

@@ -191,3 +191,32 @@ def test_largest_baseline_config_runs(dev):
         if "qkv_b" in name:
             continue                                   # its key third is analytically zero
         assert float(g.abs().max()) > 0, name
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_captured_step_replays_bitwise(dev, precision):
+    """engine.capture_train_step: the whole step (forward, loss, backward, Adam) as ONE hipGraph.  Replaying it on new
+    batches must give bit for bit what eager launches give (same kernels, same order, step counter on the device), must
+    not disturb the trajectory by having been captured, and must agree with the host-counter Adam path to rounding."""
+    from vlg.engine import LayoutEngine
+    from vlg.spec import LayoutConfig
+    cfg = LayoutConfig(B=2, T=16, N=12, d=256, n_layers=2)
+    batches = [to_dev(O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=90 + i), dev) for i in range(4)]
+    eager = LayoutEngine(cfg, dev, precision=precision)
+    eager.use_device_step_counter()
+    host = LayoutEngine(cfg, dev, precision=precision)              # Adam factors computed on the host each step
+    graphed = LayoutEngine(cfg, dev, precision=precision)
+    run = graphed.capture_train_step(batches[0])
+    assert torch.equal(graphed.params, eager.params) and graphed.step_count == 0, "capturing must not take a step"
+    for b in batches:
+        le = eager.train_step(b).clone()
+        lh = host.train_step(b).clone()
+        lg = run(b).clone()
+        assert torch.equal(le, lg), (le, lg)
+        assert_close(lh, le, rtol=1e-6, atol=1e-6, what="loss, host vs device step counter")
+    assert torch.equal(graphed.params, eager.params) and torch.equal(graphed.exp_avg_sq, eager.exp_avg_sq)
+    assert graphed.step_count == eager.step_count == 4
+    assert int(graphed.adam_state.view(torch.int32)[2]) == 4
+    assert_close(host.params, eager.params, rtol=1e-5, atol=1e-7, what="params, host vs device step counter")
+    if precision == "bf16":
+        assert torch.equal(graphed.params_bf16, graphed.params.to(torch.bfloat16))

@@ -61,7 +61,11 @@ __global__ __launch_bounds__(256) void reduce_slabs_tall_kernel(const float* __r
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                    float beta1, float beta2, float eps, float step_size,
-                                                   float sqrt_bc2, float grad_scale, bf16_t* __restrict__ shadow) {
+                                                   float sqrt_bc2, float grad_scale, bf16_t* __restrict__ shadow,
+                                                   const float* __restrict__ coef_dev) {
+    // captured-graph mode: the bias-correction factors of THIS step live in device memory (adam_state_kernel), because a
+    // replayed launch cannot take new by-value arguments
+    if (coef_dev != nullptr) { step_size = coef_dev[0]; sqrt_bc2 = coef_dev[1]; }
     const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
     (void)beta1;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
@@ -190,7 +194,7 @@ static int adam_launch(float* param, const float* grad, float* exp_avg, float* e
     const float step_size = (float)((double)lr / bc1);
     const float sqrt_bc2 = (float)sqrt(bc2);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       exp_avg, exp_avg_sq, n / 4, beta1, beta2, eps, step_size, sqrt_bc2, grad_scale, shadow);
+                       exp_avg, exp_avg_sq, n / 4, beta1, beta2, eps, step_size, sqrt_bc2, grad_scale, shadow, (const float*)nullptr);
     return vlg_last_error();
 }
 
@@ -206,4 +210,30 @@ extern "C" int vlg_adam_step_bf16(float* param, const float* grad, float* exp_av
     if (!shadow) return VLG_ERR_SHAPE;
     return adam_launch(param, grad, exp_avg, exp_avg_sq, reinterpret_cast<bf16_t*>(shadow), n, step, lr, beta1, beta2, eps,
                        grad_scale, stream);
+}
+
+// ---- Adam with its step counter on the device (hipGraph replay: vlg/engine.py capture_train_step)
+// state = {float step_size, float sqrt_bc2, int step, int pad}: one thread advances the counter and recomputes the two
+// factors in double, exactly as adam_launch does on the host.
+__global__ void adam_state_kernel(float* state, float lr, float beta1, float beta2, int advance) {
+    int* istate = reinterpret_cast<int*>(state);
+    const int step = istate[2] + (advance ? 1 : 0);
+    istate[2] = step;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    state[0] = (float)((double)lr / bc1);
+    state[1] = (float)sqrt(bc2);
+}
+
+extern "C" int vlg_adam_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, vlg_bf16* shadow,
+                                   int64_t n, float* state, int advance, float lr, float beta1, float beta2, float eps,
+                                   float grad_scale, void* stream) {
+    if (n < 4 || (n & 3) || !state) return VLG_ERR_SHAPE;
+    if (!vlg_aligned16(param) || !vlg_aligned16(grad) || !vlg_aligned16(exp_avg) || !vlg_aligned16(exp_avg_sq) ||
+        !vlg_aligned16(state) || (shadow && !vlg_aligned8(shadow))) return VLG_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_state_kernel, dim3(1), dim3(1), 0, s, state, lr, beta1, beta2, advance);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n / 4,
+                       beta1, beta2, eps, 0.f, 1.f, grad_scale, reinterpret_cast<bf16_t*>(shadow), (const float*)state);
+    return vlg_last_error();
 }

@@ -92,6 +92,7 @@ class LayoutEngine:
         self.exp_avg = torch.zeros(self.n_params, **f32)
         self.exp_avg_sq = torch.zeros(self.n_params, **f32)
         self.step_count = 0
+        self.adam_state = None                       # device-side {step_size, sqrt_bc2, step} once a step is captured in a hipGraph
         # bf16 mode: a bf16 copy of the weights feeds the projections (the Adam kernel refreshes it with every update)
         self.params_bf16 = torch.zeros(self.n_params, dtype=torch.bfloat16, device=device) if self.bf16_store else None
         self.load_params(init_params(cfg, seed))
@@ -110,6 +111,10 @@ class LayoutEngine:
     def pw(self, name: str) -> torch.Tensor:
         """weight operand of a projection: the fp32 master, or its bf16 shadow in the bf16 mode"""
         return self.view(self.params_bf16 if self.bf16_store else self.params, name)
+
+    def _sync_device_step(self) -> None:
+        if self.adam_state is not None:
+            self.adam_state.view(torch.int32)[2] = int(self.step_count)
 
     def _refresh_shadow(self) -> None:
         if self.params_bf16 is not None:
@@ -142,6 +147,7 @@ class LayoutEngine:
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
+        self._sync_device_step()
 
     def optimizer_state(self) -> Dict[str, object]:
         """Adam state for the checkpoint's 'optimizer' entry (flat tensors, CPU)."""
@@ -154,6 +160,7 @@ class LayoutEngine:
         self.exp_avg.copy_(st["exp_avg"])
         self.exp_avg_sq.copy_(st["exp_avg_sq"])
         self.step_count = int(st["step"])
+        self._sync_device_step()
 
     # ------------------------------------------------------------------- workspace
     def _alloc_workspace(self, tokens: int) -> None:
@@ -363,14 +370,68 @@ class LayoutEngine:
         if advance:
             self.step_count += 1
         o = 4 * lo
+        shadow = self.params_bf16.data_ptr() + o // 2 if self.params_bf16 is not None else 0
+        if self.adam_state is not None:          # captured / capturable step: the counter and its factors live on the device
+            call("vlg_adam_step_graph", self.params.data_ptr() + o, self.grads.data_ptr() + o, self.exp_avg.data_ptr() + o,
+                 self.exp_avg_sq.data_ptr() + o, shadow, hi - lo, ptr(self.adam_state), 1 if advance else 0, self.lr,
+                 self.beta1, ADAM_BETA2, ADAM_EPS, grad_scale, self._stream())
+            return
         if self.params_bf16 is not None:
             call("vlg_adam_step_bf16", self.params.data_ptr() + o, self.grads.data_ptr() + o, self.exp_avg.data_ptr() + o,
-                 self.exp_avg_sq.data_ptr() + o, self.params_bf16.data_ptr() + o // 2, hi - lo, self.step_count, self.lr,
+                 self.exp_avg_sq.data_ptr() + o, shadow, hi - lo, self.step_count, self.lr,
                  self.beta1, ADAM_BETA2, ADAM_EPS, grad_scale, self._stream())
             return
         call("vlg_adam_step", self.params.data_ptr() + o, self.grads.data_ptr() + o, self.exp_avg.data_ptr() + o,
              self.exp_avg_sq.data_ptr() + o, hi - lo, self.step_count, self.lr, self.beta1, ADAM_BETA2, ADAM_EPS,
              grad_scale, self._stream())
+
+    # ------------------------------------------------------------------- hipGraph
+    def use_device_step_counter(self) -> None:
+        """Move Adam's step counter (and the bias-correction factors derived from it) to device memory, the form a
+        captured step needs; the host count `step_count` keeps mirroring it."""
+        if self.adam_state is None:
+            st = torch.zeros(4, dtype=torch.float32, device=self.device)
+            st.view(torch.int32)[2] = int(self.step_count)
+            self.adam_state = st
+
+    def capture_train_step(self, example_batch: Dict[str, torch.Tensor]):
+        """Capture forward -> loss -> backward -> Adam for this batch SHAPE in one hipGraph (single process: the
+        data-parallel hooks are not captured) and return `run(batch) -> loss scalars`: it copies the batch into the
+        graph's static input buffers and replays ~110 kernel launches with one host call.  Everything the step
+        touches is preallocated and no launch argument changes between steps (the Adam step counter moves to the
+        device), so replay is bitwise identical to the eager step."""
+        self._check_batch(example_batch)
+        self.use_device_step_counter()
+        static = {k: example_batch[k].clone() for k in ("slot_class", "slot_box", "tgt_class", "tgt_box", "valid")}
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        keep = (self.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone(), self.step_count)
+        with torch.cuda.stream(side):            # warm-up on a side stream, as stream capture requires
+            self.train_step(static)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        # undo the warm-up step: capture must not change the training trajectory
+        self.params.copy_(keep[0]); self.exp_avg.copy_(keep[1]); self.exp_avg_sq.copy_(keep[2])
+        self.adam_state.copy_(keep[3]); self.step_count = keep[4]
+        self._refresh_shadow()
+        timer, self.timer = self.timer, None     # events are not capturable work
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            self.train_step(static)
+        self.timer = timer
+        self.params.copy_(keep[0]); self.exp_avg.copy_(keep[1]); self.exp_avg_sq.copy_(keep[2])
+        self.adam_state.copy_(keep[3]); self.step_count = keep[4]
+        self._refresh_shadow()
+
+        def run(batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+            for k, t in static.items():
+                if batch[k] is not t:
+                    t.copy_(batch[k], non_blocking=True)
+            graph.replay()
+            self.step_count += 1
+            return self.loss_out
+        run.graph, run.static_batch = graph, static
+        return run
 
     # ---------------------------------------------------------------- public views
     def outputs_btn(self) -> tuple:

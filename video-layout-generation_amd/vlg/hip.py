@@ -46,6 +46,7 @@ SIGNATURES = {
     "vlg_reduce_slabs_table": (I, [P, I, I, P]),
     "vlg_sum_partials_table": (I, [P, I, P]),
     "vlg_adam_step": (I, [P, P, P, P, L, I, F, F, F, F, F, P]),
+    "vlg_adam_step_graph": (I, [P, P, P, P, P, L, P, I, F, F, F, F, F, P]),
     "vlg_adam_step_bf16": (I, [P, P, P, P, P, L, I, F, F, F, F, F, P]),
     "vlg_image_loss_scratch": (I, []),
     "vlg_ce_nchw": (I, [P, P, P, P, P, I, I, L, F, P]),
