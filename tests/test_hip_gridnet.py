@@ -170,3 +170,25 @@ def test_upsample_matches_torch(dev):
     dxo = torch.empty(b, C, h, w, device=dev)
     hip.call("vlg_padded_to_nchw", tgi.ptr, dxo.data_ptr(), b, C, h, w, tgi.cp, S)
     assert_close(dxo, x.grad, rtol=1e-5, atol=1e-5, what="upsample bwd")
+
+
+def test_fill_coords_matches_reference_addcoords(dev):
+    """The two constant channels vlg_fill_coords writes into a padded tensor are, bit for bit, what the reference's own
+    AddCoords module appends (tests/golden/addcoords.npz, captured by oracle/make_golden_addcoords.py from
+    models.modules.AddCoords, reference src/models/modules.py:65-96): first channel varies along H, second along W."""
+    import numpy as np
+    from conftest import GOLDEN
+    from vlg import hip
+    from vlg.gridnet import _Geo, _PT
+    want = torch.from_numpy(np.load(GOLDEN + "/addcoords.npz")["coord_channels"])       # (2, 256, 256)
+    b, H, W, C = 2, 256, 256, 5
+    geo = _Geo(b, H, W, dev)
+    t = _PT(geo, C, dev, coord=True)
+    S = torch.cuda.current_stream().cuda_stream
+    hip.call("vlg_fill_coords", t.ptr, b, H, W, t.cp, t.coord_c0, S)
+    out = torch.empty(b, C + 2, H, W, device=dev)
+    hip.call("vlg_padded_to_nchw", t.ptr, out.data_ptr(), b, C + 2, H, W, t.cp, S)
+    got = out.cpu()
+    for n in range(b):
+        assert torch.equal(got[n, C:], want), "coordinate channels differ from the reference module's"
+    assert float(got[:, :C].abs().max()) == 0.0
