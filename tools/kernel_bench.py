@@ -39,7 +39,10 @@ def main():
     y_d, y_3d, y_ff = r(M, d), r(M, 3 * d), r(M, ff)
     w_qkv, w_proj, w_ff1, w_ff2 = r(3 * d, d), r(d, d), r(ff, d), r(d, ff)
     bias = r(ff)
-    slabs = torch.empty(64 * (ff * d + ff), device=dev)
+    # sized from the library's own split plan (never a guess: a short buffer here is an out-of-bounds GPU write)
+    need = max(lib.vlg_linear_wgrad_slabs_for(M, n, k, fl_) * (n * k + n) for (n, k) in ((3 * d, d), (d, d), (ff, d), (d, ff))
+               for fl_ in (0, 16, 256))
+    slabs = torch.empty(need + 1024, device=dev)
     red_dst = torch.empty(ff * d + ff, device=dev)            # reduce target: [w | b] of the largest projection
     stats = r(2, M)
     g = r(d)
