@@ -24,6 +24,9 @@
 
 #include <stdint.h>
 
+/* Every entry point that writes per-block partial sums ("slabs") takes slab_capacity = the number of floats available at
+ * `slabs`; it is checked against slab count x slab_stride on the host BEFORE the launch (VLG_ERR_SHAPE), so a short buffer
+ * can never become an out-of-bounds device write. */
 typedef uint16_t vlg_bf16;    /* bfloat16 bit pattern (activation storage of the bf16 mode) */
 
 #ifdef __cplusplus
@@ -53,7 +56,7 @@ int vlg_embed_fwd(const int64_t* slot_class, const float* slot_box,
                   int B, int T, int N, int d, int vocab, void* stream);
 int vlg_embed_bwd_slabs(void);             /* number of slabs vlg_embed_bwd writes */
 int vlg_embed_bwd(const float* dx, const int64_t* slot_class, const float* slot_box,
-                  float* slabs, int64_t slab_stride,
+                  float* slabs, int64_t slab_stride, int64_t slab_capacity,
                   int B, int T, int N, int d, int vocab, void* stream);
 
 /* ------------------------------------------------------------------ layer-norm
@@ -69,12 +72,12 @@ int vlg_layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta
 int vlg_layernorm_bwd_slabs(int64_t rows);
 int vlg_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                       const float* gamma, const float* dres, float* dx_out,
-                      float* slabs, int64_t slab_stride,
+                      float* slabs, int64_t slab_stride, int64_t slab_capacity,
                       int64_t rows, int d, void* stream);
 /* same, dy read as bf16 (it comes out of a projection's data gradient); x, dres, dx stay fp32 */
 int vlg_layernorm_bwd_bf16(const vlg_bf16* dy, const float* x, const float* mean, const float* rstd,
                            const float* gamma, const float* dres, float* dx_out,
-                           float* slabs, int64_t slab_stride,
+                           float* slabs, int64_t slab_stride, int64_t slab_capacity,
                            int64_t rows, int d, void* stream);
 
 /* ------------------------------------------------------------------------ GEMM
@@ -111,7 +114,7 @@ int vlg_linear_dgrad(const void* dY, int ldy, const void* W, int ldw,
 int vlg_linear_wgrad_slabs(int64_t M, int N, int K);                 /* slab count of a flags = 0 launch */
 int vlg_linear_wgrad_slabs_for(int64_t M, int N, int K, int flags);  /* slab count of a launch with these flags */
 int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
-                     float* slabs, int64_t slab_stride,
+                     float* slabs, int64_t slab_stride, int64_t slab_capacity,
                      int64_t M, int N, int K, int flags /* VLG_EPI_BF16 | storage bits */, void* stream);
 
 /* ------------------------------------------------------------------- attention
@@ -238,7 +241,7 @@ int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, const float
                       void* stream);
 int vlg_conv3x3_dgrad_splits(int64_t rows_in, int cin_p, int cout_p);
 int vlg_conv3x3_wgrad_slabs(int64_t rows, int cin_p, int cout_p);
-int vlg_conv3x3_wgrad(const float* dout, const float* in, float* slabs, int64_t slab_stride,
+int vlg_conv3x3_wgrad(const float* dout, const float* in, float* slabs, int64_t slab_stride, int64_t slab_capacity,
                       const int* rowtab, const float* prelu_slope, int64_t rows, int cin_p, int cout_p,
                       int wp_in, int act_ch, void* stream);
 /* (b,C,H,W) <-> padded NHWC; to_padded can append AddCoords' two channels (modules.py:65-96) at c0, c0+1 */

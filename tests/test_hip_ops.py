@@ -59,7 +59,7 @@ def test_embed_fwd_bwd(H, dev, B, T, N, d):
     L = vocab * d + d * 4 + d + T * d
     ns = H.load().vlg_embed_bwd_slabs()
     slabs = torch.empty(ns * L, device=dev)
-    H.call("vlg_embed_bwd", dx.data_ptr(), clsd.data_ptr(), boxd.data_ptr(), slabs.data_ptr(), L, B, T, N, d, vocab,
+    H.call("vlg_embed_bwd", dx.data_ptr(), clsd.data_ptr(), boxd.data_ptr(), slabs.data_ptr(), L, slabs.numel(), B, T, N, d, vocab,
            stream())
     g = reduce_slabs(H, slabs, L, ns, L, dev)
     o = 0
@@ -92,7 +92,7 @@ def test_layernorm_fwd_bwd(H, dev, rows, d):
     dres = res.to(dev)
     dyd = dy.to(dev)
     H.call("vlg_layernorm_bwd", dyd.data_ptr(), xd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
-           dres.data_ptr(), dres.data_ptr(), slabs.data_ptr(), 2 * d, rows, d, stream())      # in place
+           dres.data_ptr(), dres.data_ptr(), slabs.data_ptr(), 2 * d, slabs.numel(), rows, d, stream())      # in place
     assert_close(dres, res + x.grad, rtol=1e-4, atol=2e-5, what="ln dx (+residual, in place)")
     gb = reduce_slabs(H, slabs, 2 * d, ns, 2 * d, dev)
     assert_close(gb[:d], g.grad, rtol=1e-4, atol=1e-4, what="ln dgamma")
@@ -100,7 +100,7 @@ def test_layernorm_fwd_bwd(H, dev, rows, d):
     # without residual
     dx2 = torch.empty(rows, d, device=dev)
     H.call("vlg_layernorm_bwd", dyd.data_ptr(), xd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
-           0, dx2.data_ptr(), slabs.data_ptr(), 2 * d, rows, d, stream())
+           0, dx2.data_ptr(), slabs.data_ptr(), 2 * d, slabs.numel(), rows, d, stream())
     assert_close(dx2, x.grad, rtol=1e-4, atol=2e-5, what="ln dx")
 
 
@@ -156,7 +156,7 @@ def test_linear_dgrad_wgrad(H, dev, M, N, K):
     ns = H.load().vlg_linear_wgrad_slabs(M, N, K)
     stride = N * K + N
     slabs = torch.full((ns * stride,), float("nan"), device=dev)
-    H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, M, N, K, 0, stream())
+    H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, slabs.numel(), M, N, K, 0, stream())
     g = reduce_slabs(H, slabs, stride, ns, stride, dev)
     sc = math.sqrt(M)
     assert_close(g[:N * K].view(N, K) / sc, (dy.double().t() @ x.double()).float() / sc, rtol=1e-4, atol=1e-5, what="wgrad")
@@ -296,7 +296,7 @@ def test_layernorm_bf16_storage(H, dev, rows, d):
     res = torch.randn(rows, d)
     dres, dyd = res.to(dev), dy.to(dev).to(BF)
     H.call("vlg_layernorm_bwd_bf16", dyd.data_ptr(), xd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
-           dres.data_ptr(), dres.data_ptr(), slabs.data_ptr(), 2 * d, rows, d, stream())
+           dres.data_ptr(), dres.data_ptr(), slabs.data_ptr(), 2 * d, slabs.numel(), rows, d, stream())
     assert_close(dres, res + x.grad, rtol=1e-4, atol=2e-5, what="ln dx from bf16 dy")
     gb = reduce_slabs(H, slabs, 2 * d, ns, 2 * d, dev)
     assert_close(gb[:d], g.grad, rtol=1e-4, atol=1e-4, what="ln dgamma from bf16 dy")
@@ -372,7 +372,7 @@ def test_linear_bf16_storage(H, dev, M, N, K):
     sc = math.sqrt(M)
     for dy_dev, bits, tag in ((dy.to(dev), 0, "fp32 dY"), (dy.to(dev).to(BF), H.EPI_A_BF16, "bf16 dY")):
         slabs = torch.full((ns * stride,), float("nan"), device=dev)
-        H.call("vlg_linear_wgrad", dy_dev.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, M, N, K,
+        H.call("vlg_linear_wgrad", dy_dev.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, slabs.numel(), M, N, K,
                FL | bits | H.EPI_B_BF16, stream())
         g = reduce_slabs(H, slabs, stride, ns, stride, dev)
         assert_close(g[:N * K].view(N, K) / sc, (dy.double().t() @ x.double()).float() / sc, rtol=1e-4, atol=1e-5,
@@ -454,10 +454,33 @@ def test_linear_split3_is_fp32_grade(H, dev, M, N, K):
     ns = H.load().vlg_linear_wgrad_slabs_for(M, N, K, S3)
     stride = N * K + N
     slabs = torch.full((ns * stride,), float("nan"), device=dev)
-    H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, M, N, K, S3, stream())
+    H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), stride, slabs.numel(), M, N, K, S3, stream())
     g = reduce_slabs(H, slabs, stride, ns, stride, dev)
     sc = math.sqrt(M)
     assert_close(g[:N * K].view(N, K) / sc, (dy.double().t() @ x.double()).float() / sc, rtol=1e-4, atol=1e-5, what="split wgrad")
     assert_close(g[N * K:] / sc, dy.double().sum(0).float() / sc, rtol=1e-4, atol=1e-5, what="split bias grad")
     with pytest.raises(H.HipError):                                  # the split is an fp32-tensor mode
         H.call("vlg_linear_dgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, 0, M, N, K, S3 | H.EPI_BF16, stream())
+
+
+def test_short_slab_buffers_are_refused(H, dev):
+    """Every slab producer checks `slab_capacity` against slab count x stride on the host and refuses the launch
+    (VLG_ERR_SHAPE) - an undersized buffer must never become an out-of-bounds device write."""
+    M, N, K, d = 4096, 256, 128, 128
+    dy, x = torch.randn(M, N, device=dev), torch.randn(M, K, device=dev)
+    lib = H.load()
+    ns = lib.vlg_linear_wgrad_slabs(M, N, K)
+    stride = N * K + N
+    slabs = torch.empty(ns * stride, device=dev)
+    with pytest.raises(H.HipError):
+        H.call("vlg_linear_wgrad", dy.data_ptr(), N, x.data_ptr(), K, slabs.data_ptr(), stride, ns * stride - 1, M, N, K, 0, stream())
+    H.call("vlg_linear_wgrad", dy.data_ptr(), N, x.data_ptr(), K, slabs.data_ptr(), stride, ns * stride, M, N, K, 0, stream())
+    xs = torch.randn(M, d, device=dev)
+    mean, rstd, g = torch.zeros(M, device=dev), torch.ones(M, device=dev), torch.ones(d, device=dev)
+    nl = lib.vlg_layernorm_bwd_slabs(M)
+    ls = torch.empty(nl * 2 * d, device=dev)
+    out = torch.empty(M, d, device=dev)
+    with pytest.raises(H.HipError):
+        H.call("vlg_layernorm_bwd", xs.data_ptr(), xs.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), 0, out.data_ptr(),
+               ls.data_ptr(), 2 * d, nl * 2 * d - 1, M, d, stream())
+    torch.cuda.synchronize()

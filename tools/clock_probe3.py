@@ -25,7 +25,7 @@ for nm, n, k, dy, xx in (("wgrad qkv", 3 * d, d, x_3d, x_d), ("wgrad ff1", ff, d
     ns = lib.vlg_linear_wgrad_slabs(M, n, k)
     per = (M + ns - 1) // ns
     per = (per + 31) // 32 * 32
-    cases[nm] = ((lambda n=n, k=k, dy=dy, xx=xx: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, M, n, k, 0, S)), n, k, per // 32)
+    cases[nm] = ((lambda n=n, k=k, dy=dy, xx=xx: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, slabs.numel(), M, n, k, 0, S)), n, k, per // 32)
 for name, (run, n, k, nk) in cases.items():
     for _ in range(200):
         run()

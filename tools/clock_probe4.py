@@ -16,7 +16,7 @@ P = lambda t: t.data_ptr()
 x_d, x_ff = r(M, d), r(M, ff)
 slabs = torch.empty(160 * (ff * d + ff), device=dev)
 n, k = ff, d
-run = lambda: hip.call("vlg_linear_wgrad", P(x_ff), n, P(x_d), k, P(slabs), n * k + n, M, n, k, 0, S)
+run = lambda: hip.call("vlg_linear_wgrad", P(x_ff), n, P(x_d), k, P(slabs), n * k + n, slabs.numel(), M, n, k, 0, S)
 for _ in range(300):
     run()
 torch.cuda.synchronize()

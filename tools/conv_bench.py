@@ -59,7 +59,7 @@ for (hw, cin, cout) in SHAPES:
     # da = NULL when the split-K path exists (frozen trunks ask for no slope gradient), else the GridNet form
     d = timeit(lambda: call("vlg_conv3x3_dgrad", y.ptr, ptr(w), dx.ptr, x.ptr, ptr(geo.mask), ptr(zero), 0 if dsp > 1 else ptr(da),
                             0, 0, geo.rows, x.cp, y.cp, geo.wp, x.cp, 8, hip.ptr(dws), stream))
-    g = timeit(lambda: call("vlg_conv3x3_wgrad", y.ptr, x.ptr, ptr(slabs), slab_stride, 0, ptr(zero), geo.rows, x.cp, y.cp,
+    g = timeit(lambda: call("vlg_conv3x3_wgrad", y.ptr, x.ptr, ptr(slabs), slab_stride, slabs.numel(), 0, ptr(zero), geo.rows, x.cp, y.cp,
                             geo.wp, x.cp, stream))
     print("     %4dx%-4d %3d->%-3d %7.1f us %5.1f  %7.1f us %5.1f  %7.1f us %5.1f  (%d slabs%s)" % (
         hw, hw, cin, cout, f * 1e6, flop / f / 1e12, d * 1e6, flop / d / 1e12, g * 1e6, flop / g / 1e12, n_slab,

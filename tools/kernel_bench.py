@@ -65,12 +65,12 @@ def main():
     add("gemm dgrad ff2 (dgelu)", fl(d, ff), "F", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(y_ff), ff, P(x_ff2), M, d, ff, EPI_DGELU | FLAGS, S))
     for nm, n, k, dy, xx in (("qkv", 3 * d, d, x_3d, x_d), ("proj", d, d, y_d, x_d), ("ff1", ff, d, x_ff, x_d), ("ff2", d, ff, x_d, x_ff)):
         ns = lib.vlg_linear_wgrad_slabs_for(M, n, k, FLAGS)
-        add("gemm wgrad %-4s (%d slabs)" % (nm, ns), fl(n, k), "F", lambda n=n, k=k, dy=dy, xx=xx: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, M, n, k, FLAGS, S))
+        add("gemm wgrad %-4s (%d slabs)" % (nm, ns), fl(n, k), "F", lambda n=n, k=k, dy=dy, xx=xx: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, slabs.numel(), M, n, k, FLAGS, S))
         add("reduce wgrad %-4s" % nm, 4.0 * (n * k + n) * (ns + 1), "B", lambda n=n, k=k, ns=ns: hip.call("vlg_reduce_slabs", P(slabs), n * k + n, ns, P(red_dst), n * k + n, S))
     add("attention fwd", 16.0 * M * d, "B", lambda: hip.call("vlg_attention_fwd", P(x_3d), P(y_d), B * N, T, d, S))
     add("attention bwd", 28.0 * M * d, "B", lambda: hip.call("vlg_attention_bwd", P(x_3d), P(x_d), P(y_3d), B * N, T, d, S))
     add("layernorm fwd", 8.0 * M * d, "B", lambda: hip.call("vlg_layernorm_fwd", P(x_d), P(g), P(g), P(y_d), P(stats[0]), P(stats[1]), M, d, 1e-5, S))
-    add("layernorm bwd", 16.0 * M * d, "B", lambda: hip.call("vlg_layernorm_bwd", P(x_d), P(y_d), P(stats[0]), P(stats[1]), P(g), P(x_d), P(y_d), P(slabs), 2 * d, M, d, S))
+    add("layernorm bwd", 16.0 * M * d, "B", lambda: hip.call("vlg_layernorm_bwd", P(x_d), P(y_d), P(stats[0]), P(stats[1]), P(g), P(x_d), P(y_d), P(slabs), 2 * d, slabs.numel(), M, d, S))
 
     if a.bf16store:
         from vlg.hip import EPI_A_BF16 as AB, EPI_B_BF16 as BB, EPI_OUT_BF16 as OB, EPI_BF16 as FL
@@ -95,11 +95,11 @@ def main():
         for nm, n, k, dy, xx, bits, nb in (("qkv  bf16,bf16", 3 * d, d, h3, hd, AB | BB, by(6 * E, 2 * E)), ("proj f32,bf16", d, d, y_d, hd, BB, by(4 * E, 2 * E)),
                                            ("ff1  bf16,bf16", ff, d, hf, hd, AB | BB, by(8 * E, 2 * E)), ("ff2  f32,bf16", d, ff, x_d, hf, BB, by(4 * E, 8 * E))):
             ns = lib.vlg_linear_wgrad_slabs_for(M, n, k, FL)
-            add("wgrad %s (%d slabs)" % (nm, ns), nb + 4.0 * ns * (n * k + n), "B", lambda n=n, k=k, dy=dy, xx=xx, bits=bits: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, M, n, k, FL | bits, S))
+            add("wgrad %s (%d slabs)" % (nm, ns), nb + 4.0 * ns * (n * k + n), "B", lambda n=n, k=k, dy=dy, xx=xx, bits=bits: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, slabs.numel(), M, n, k, FL | bits, S))
         add("attention fwd bf16", 8.0 * M * d, "B", lambda: hip.call("vlg_attention_fwd_bf16", P(h3), P(od), B * N, T, d, S))
         add("attention bwd bf16", 14.0 * M * d, "B", lambda: hip.call("vlg_attention_bwd_bf16", P(h3), P(hd), P(o3), B * N, T, d, S))
         add("layernorm fwd ->bf16", 6.0 * M * d, "B", lambda: hip.call("vlg_layernorm_fwd_bf16", P(x_d), P(g), P(g), P(od), P(stats[0]), P(stats[1]), M, d, 1e-5, S))
-        add("layernorm bwd bf16 dy", 14.0 * M * d, "B", lambda: hip.call("vlg_layernorm_bwd_bf16", P(hd), P(y_d), P(stats[0]), P(stats[1]), P(g), P(x_d), P(x_d), P(slabs), 2 * d, M, d, S))
+        add("layernorm bwd bf16 dy", 14.0 * M * d, "B", lambda: hip.call("vlg_layernorm_bwd_bf16", P(hd), P(y_d), P(stats[0]), P(stats[1]), P(g), P(x_d), P(x_d), P(slabs), 2 * d, slabs.numel(), M, d, S))
 
     times = {c[0]: [] for c in cases}
     for rnd in range(a.rounds + 1):

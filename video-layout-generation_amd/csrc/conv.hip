@@ -519,7 +519,7 @@ extern "C" int vlg_conv3x3_wgrad_slabs(int64_t rows, int cin_p, int cout_p) {
 }
 
 extern "C" int vlg_conv3x3_wgrad(const float* dout, const float* in, float* slabs, int64_t slab_stride,
-                                 const int* rowtab, const float* prelu_slope, int64_t rows, int cin_p, int cout_p,
+                                 int64_t slab_capacity, const int* rowtab, const float* prelu_slope, int64_t rows, int cin_p, int cout_p,
                                  int wp_in, int act_ch, void* stream) {
     // slab[s][co*(9*cin_p) + tap*cin_p + ci] = sum_{p in split s} dout[p, co] * act(in[row(p) + shift(tap), ci])
     // slab[s][cout_p*9*cin_p + co]           = sum_p dout[p, co]                (bias gradient)
@@ -532,6 +532,7 @@ extern "C" int vlg_conv3x3_wgrad(const float* dout, const float* in, float* slab
     g.M = cout_p; g.N = 9 * cin_p; g.Kc = rows;
     g.lda = cout_p; g.ldb = cin_p; g.ldc = 9 * cin_p; g.cin = cin_p;
     conv_wgrad_plan(rows, cin_p, cout_p, &g.splits, &g.kc_per_split);
+    if (slab_capacity < (int64_t)g.splits * slab_stride) return VLG_ERR_SHAPE;      // the caller's buffer must hold every slab
     g.slab_stride = slab_stride; g.colsum_off = (int64_t)cout_p * 9 * cin_p; g.act_ch = act_ch;
     fill_shifts(g, wp_in, 1);
     switch (conv_wgrad_bm(cout_p)) {

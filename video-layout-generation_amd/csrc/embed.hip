@@ -132,9 +132,10 @@ extern "C" int vlg_embed_fwd(const int64_t* slot_class, const float* slot_box, c
 extern "C" int vlg_embed_bwd_slabs(void) { return EMBED_BWD_SLABS; }
 
 extern "C" int vlg_embed_bwd(const float* dx, const int64_t* slot_class, const float* slot_box,
-                             float* slabs, int64_t slab_stride, int B, int T, int N, int d, int vocab,
-                             void* stream) {
+                             float* slabs, int64_t slab_stride, int64_t slab_capacity, int B, int T, int N, int d,
+                             int vocab, void* stream) {
     if (B < 1 || N < 1 || d < 64 || d > 1024 || (d & 63) || vocab < 1) return VLG_ERR_SHAPE;
+    if (slab_capacity < (int64_t)EMBED_BWD_SLABS * slab_stride) return VLG_ERR_SHAPE;      // the caller's buffer must hold every slab
     const int64_t need = (int64_t)vocab * d + (int64_t)d * 4 + d + (int64_t)T * d;
     if (slab_stride < need || (slab_stride & 3)) return VLG_ERR_SHAPE;
     if (!vlg_aligned16(slot_box) || !vlg_aligned16(slabs)) return VLG_ERR_ALIGN;

@@ -357,7 +357,7 @@ extern "C" int vlg_linear_wgrad_slabs_for(int64_t M, int N, int K, int flags) {
 }
 
 extern "C" int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, float* slabs,
-                                int64_t slab_stride, int64_t M, int N, int K, int flags, void* stream) {
+                                int64_t slab_stride, int64_t slab_capacity, int64_t M, int N, int K, int flags, void* stream) {
     // slab[s][n*K + k] = sum_{m in split s} dY[m,n] X[m,k] ;  slab[s][N*K + n] = sum_m dY[m,n]
     if (M < 1 || N < 4 || (N & 3) || K < 4 || (K & 3) || ldy < N || ldx < K) return VLG_ERR_SHAPE;
     if (slab_stride < (int64_t)N * K + N) return VLG_ERR_SHAPE;
@@ -366,6 +366,7 @@ extern "C" int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
     g.A = dY; g.B = X; g.C = slabs;
     g.M = N; g.N = K; g.Kc = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
     wgrad_plan(M, N, K, &g.splits, &g.kc_per_split, (flags & VLG_EPI_BF16) != 0);
+    if (slab_capacity < (int64_t)g.splits * slab_stride) return VLG_ERR_SHAPE;      // the caller's buffer must hold every slab
     g.slab_stride = slab_stride; g.colsum_off = (int64_t)N * K;
     hipStream_t s = (hipStream_t)stream;
     const bool bf16 = (flags & VLG_EPI_BF16) != 0;

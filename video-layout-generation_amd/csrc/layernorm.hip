@@ -172,8 +172,9 @@ extern "C" int vlg_layernorm_bwd_slabs(int64_t rows) { return ln_bwd_blocks(rows
 
 extern "C" int vlg_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                  const float* gamma, const float* dres, float* dx_out, float* slabs,
-                                 int64_t slab_stride, int64_t rows, int d, void* stream) {
+                                 int64_t slab_stride, int64_t slab_capacity, int64_t rows, int d, void* stream) {
     if (rows < 1 || slab_stride < 2 * (int64_t)d) return VLG_ERR_SHAPE;
+    if (slab_capacity < (int64_t)ln_bwd_blocks(rows) * slab_stride) return VLG_ERR_SHAPE;   // every block writes one slab
     if (!vlg_aligned16(dy) || !vlg_aligned16(x) || !vlg_aligned16(gamma) || !vlg_aligned16(dx_out) ||
         (dres && !vlg_aligned16(dres))) return VLG_ERR_ALIGN;
     const dim3 grid(ln_bwd_blocks(rows)), block(LN_BLOCK);
@@ -199,8 +200,9 @@ extern "C" int vlg_layernorm_fwd_bf16(const float* x, const float* gamma, const 
 
 extern "C" int vlg_layernorm_bwd_bf16(const vlg_bf16* dy, const float* x, const float* mean, const float* rstd,
                                       const float* gamma, const float* dres, float* dx_out, float* slabs,
-                                      int64_t slab_stride, int64_t rows, int d, void* stream) {
+                                      int64_t slab_stride, int64_t slab_capacity, int64_t rows, int d, void* stream) {
     if (rows < 1 || slab_stride < 2 * (int64_t)d) return VLG_ERR_SHAPE;
+    if (slab_capacity < (int64_t)ln_bwd_blocks(rows) * slab_stride) return VLG_ERR_SHAPE;   // every block writes one slab
     if (!vlg_aligned8(dy) || !vlg_aligned16(x) || !vlg_aligned16(gamma) || !vlg_aligned16(dx_out) ||
         (dres && !vlg_aligned16(dres))) return VLG_ERR_ALIGN;
     const dim3 grid(ln_bwd_blocks(rows)), block(LN_BLOCK);

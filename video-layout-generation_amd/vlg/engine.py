@@ -235,7 +235,7 @@ class LayoutEngine:
         n_slabs = lib.vlg_linear_wgrad_slabs_for(M, N, K, self.gemm_flags)
         s = self._stream()
         self._timed("gemm_wgrad" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_wgrad", ptr(dy), N, ptr(x),
-                    K, ptr(self.slabs), stride, M, N, K, self.gemm_flags | self._storage_bits(dy, x), s,
+                    K, ptr(self.slabs), stride, self.slabs.numel(), M, N, K, self.gemm_flags | self._storage_bits(dy, x), s,
                     nbytes=dy.element_size() * M * N + x.element_size() * M * K + 4.0 * n_slabs * stride)
         off = self.layout[wname][0]
         call("vlg_reduce_slabs", ptr(self.slabs), stride, n_slabs, self.grads.data_ptr() + 4 * off, stride, s)
@@ -251,7 +251,7 @@ class LayoutEngine:
         n_slabs = lib.vlg_layernorm_bwd_slabs(M)
         s = self._stream()
         call("vlg_layernorm_bwd_bf16" if dy.dtype == torch.bfloat16 else "vlg_layernorm_bwd", ptr(dy), ptr(x), ptr(stat[0]), ptr(stat[1]), ptr(self.p(gname)), ptr(dres),
-             ptr(dx_out), ptr(self.slabs), 2 * d, M, d, s)
+             ptr(dx_out), ptr(self.slabs), 2 * d, self.slabs.numel(), M, d, s)
         off = self.layout[gname][0]
         call("vlg_reduce_slabs", ptr(self.slabs), 2 * d, n_slabs, self.grads.data_ptr() + 4 * off, 2 * d, s)
 
@@ -336,7 +336,7 @@ class LayoutEngine:
         lib = hip.load()
         emb_len = self.layout["l0.ln1_g"][0]
         call("vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.slabs),
-             emb_len, B, T, N, d, cfg.vocab, s)
+             emb_len, self.slabs.numel(), B, T, N, d, cfg.vocab, s)
         call("vlg_reduce_slabs", ptr(self.slabs), emb_len, lib.vlg_embed_bwd_slabs(), ptr(self.grads), emb_len, s)
         if reducer is not None:
             reducer.ready("embed")

@@ -314,6 +314,7 @@ class GridNetHIP:
                 slope = self._pp(self.p_off[op.prelu]) if op.prelu else 0
                 # weight + bias gradient
                 call("vlg_conv3x3_wgrad", dout.ptr, op.x.ptr, self.slabs.data_ptr() + 4 * op.slab_off, op.slab_stride,
+                     self.slabs.numel() - op.slab_off,
                      ptr(gx.down_rowtab) if op.stride == 2 else 0, slope, go.rows, op.x.cp, op.out.cp, gx.wp, op.act_ch, s)
                 # data gradient (skipped for the network input unless asked for)
                 if op.x is not self.x or self.need_input_grad or op.prelu:

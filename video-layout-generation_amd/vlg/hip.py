@@ -25,17 +25,17 @@ SIGNATURES = {
     "vlg_debug_set_clock_probe": (None, [P]),
     "vlg_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "vlg_embed_bwd_slabs": (I, []),
-    "vlg_embed_bwd": (I, [P, P, P, P, L, I, I, I, I, I, P]),
+    "vlg_embed_bwd": (I, [P, P, P, P, L, L, I, I, I, I, I, P]),
     "vlg_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
     "vlg_layernorm_fwd_bf16": (I, [P, P, P, P, P, P, L, I, F, P]),
     "vlg_layernorm_bwd_slabs": (I, [L]),
-    "vlg_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, L, L, I, P]),
-    "vlg_layernorm_bwd_bf16": (I, [P, P, P, P, P, P, P, P, L, L, I, P]),
+    "vlg_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, L, L, L, I, P]),
+    "vlg_layernorm_bwd_bf16": (I, [P, P, P, P, P, P, P, P, L, L, L, I, P]),
     "vlg_linear_fwd": (I, [P, I, P, I, P, P, I, P, P, L, I, I, I, P]),
     "vlg_linear_dgrad": (I, [P, I, P, I, P, I, P, L, I, I, I, P]),
     "vlg_linear_wgrad_slabs": (I, [L, I, I]),
     "vlg_linear_wgrad_slabs_for": (I, [L, I, I, I]),
-    "vlg_linear_wgrad": (I, [P, I, P, I, P, L, L, I, I, I, P]),
+    "vlg_linear_wgrad": (I, [P, I, P, I, P, L, L, L, I, I, I, P]),
     "vlg_attention_fwd": (I, [P, P, L, I, I, P]),
     "vlg_attention_bwd": (I, [P, P, P, L, I, I, P]),
     "vlg_attention_fwd_bf16": (I, [P, P, L, I, I, P]),
@@ -61,7 +61,7 @@ SIGNATURES = {
     "vlg_conv3x3_dgrad": (I, [P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, P, P]),
     "vlg_conv3x3_dgrad_splits": (I, [L, I, I]),
     "vlg_conv3x3_wgrad_slabs": (I, [L, I, I]),
-    "vlg_conv3x3_wgrad": (I, [P, P, P, L, P, P, L, I, I, I, I, P]),
+    "vlg_conv3x3_wgrad": (I, [P, P, P, L, L, P, P, L, I, I, I, I, P]),
     "vlg_nchw_to_padded": (I, [P, P, I, I, I, I, I, I, P]),
     "vlg_padded_to_nchw": (I, [P, P, I, I, I, I, I, P]),
     "vlg_fill_coords": (I, [P, I, I, I, I, I, P]),
