@@ -228,7 +228,7 @@ int vlg_conv3x3_fwd(const float* in, const float* w, const float* bias, float* o
                     const float* rowmask, const float* prelu_slope, const int* rowtab, int64_t rows_out,
                     int cin_p, int cout, int cout_p, int wp_in, int act_ch, int epilogue,
                     float* workspace /* NULL, or >= vlg_conv3x3_fwd_splits() * rows_out * cout_p floats: enables split-K */,
-                    void* stream);
+                    int64_t workspace_capacity /* floats available at workspace (checked) */, void* stream);
 /* K ranges the forward uses when given a workspace (1 = no split): coarse levels of the 256-512 channel trunks */
 int vlg_conv3x3_fwd_splits(int64_t rows_out, int cin_p, int cout, int cout_p);
 int vlg_conv3x3_dgrad_slabs(int64_t rows_in, int cin_p);   /* length of the slope-gradient partial vector */
@@ -238,7 +238,8 @@ int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, const float
                       int wp, int act_ch, int epilogue,
                       float* workspace /* NULL, or >= vlg_conv3x3_dgrad_splits() * rows_in * cin_p floats (split-K; used only
                                           when da_slab and tap_tables are NULL, i.e. by the frozen trunks) */,
-                      void* stream);
+                      int64_t workspace_capacity /* floats available at workspace (checked) */,
+                      int da_capacity /* floats available at da_slab, >= vlg_conv3x3_dgrad_slabs() (checked) */, void* stream);
 int vlg_conv3x3_dgrad_splits(int64_t rows_in, int cin_p, int cout_p);
 int vlg_conv3x3_wgrad_slabs(int64_t rows, int cin_p, int cout_p);
 int vlg_conv3x3_wgrad(const float* dout, const float* in, float* slabs, int64_t slab_stride, int64_t slab_capacity,

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void conv_finish_dgrad_kernel(const float* __r
 extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bias, float* out, const float* resid,
                                const float* rowmask, const float* prelu_slope, const int* rowtab, int64_t rows_out,
                                int cin_p, int cout, int cout_p, int wp_in, int act_ch, int epilogue, float* workspace,
-                               void* stream) {
+                               int64_t workspace_capacity, void* stream) {
     if (rows_out < 1 || cin_p < 32 || (cin_p & 31) || cout < 1 || cout > cout_p || (cout_p & 31)) return VLG_ERR_SHAPE;
     if (!conv_ok(in) || !conv_ok(w) || !conv_ok(out)) return VLG_ERR_ALIGN;
     if ((epilogue & VLG_CEPI_RESID) && !resid) return VLG_ERR_SHAPE;
@@ -415,6 +415,7 @@ extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bia
     const int splits = workspace != nullptr ? conv_fwd_splits(rows_out, cin_p, cout, cout_p) : 1;
     if (splits > 1) {
         if (!vlg_aligned16(workspace) || (epilogue & VLG_CEPI_PRELU)) return VLG_ERR_ALIGN;
+        if (workspace_capacity < (int64_t)splits * rows_out * cout_p) return VLG_ERR_SHAPE;     // host-side bound on the partial tiles
         const int ktiles = 9 * cin_p / 32;
         g.splits = splits;
         g.kc_per_split = (int64_t)((ktiles + splits - 1) / splits) * 32;
@@ -452,13 +453,15 @@ extern "C" int vlg_conv3x3_dgrad_splits(int64_t rows_in, int cin_p, int cout_p) 
 extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, const float* x_in,
                                  const float* rowmask_in, const float* prelu_slope, float* da_slab,
                                  const int* tap_tables, int64_t tab_stride, int64_t rows_in, int cin_p, int cout_p,
-                                 int wp, int act_ch, int epilogue, float* workspace, void* stream) {
+                                 int wp, int act_ch, int epilogue, float* workspace, int64_t workspace_capacity,
+                                 int da_capacity, void* stream) {
     // din[p, ci] = mask[p] * sum_tap sum_co dout[p - shift(tap), co] * W[co][tap][ci]   (stride 1)
     // stride 2: tap_tables[tap][p] = output row feeding input row p through that tap (or a zero guard row)
     if (rows_in < 1 || cin_p < 32 || (cin_p & 31) || (cin_p > 128 && (cin_p & 127)) || cout_p < 32 || (cout_p & 31))
         return VLG_ERR_SHAPE;                                // wide inputs are tiled 128 columns at a time
     if (!conv_ok(dout) || !conv_ok(w) || !conv_ok(din)) return VLG_ERR_ALIGN;
     if ((epilogue & VLG_CEPI_DPRELU) && (!x_in || !prelu_slope)) return VLG_ERR_SHAPE;
+    if (da_slab != nullptr && da_capacity < vlg_conv3x3_dgrad_slabs(rows_in, cin_p)) return VLG_ERR_SHAPE;   // one partial per block
     ConvArgs g{};
     g.A = dout; g.B = w; g.C = din; g.aux_in = x_in; g.rowmask = rowmask_in; g.prelu = prelu_slope; g.da_slab = da_slab;
     g.rowtab = tap_tables; g.tab_stride = tap_tables ? tab_stride : 0;
@@ -471,6 +474,7 @@ extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, 
     const int splits = (workspace != nullptr && da_slab == nullptr && tap_tables == nullptr) ? conv_dgrad_splits(rows_in, cin_p, cout_p) : 1;
     if (splits > 1) {
         if (!vlg_aligned16(workspace)) return VLG_ERR_ALIGN;
+        if (workspace_capacity < (int64_t)splits * rows_in * cin_p) return VLG_ERR_SHAPE;
         const int ktiles = 9 * cout_p / 32;
         g.splits = splits;
         g.kc_per_split = (int64_t)((ktiles + splits - 1) / splits) * 32;

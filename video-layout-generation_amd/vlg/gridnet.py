@@ -275,7 +275,7 @@ class GridNetHIP:
                 call("vlg_conv3x3_fwd", op.x.ptr, self._pp(op.w_off), self._pp(op.b_off), op.out.ptr,
                      op.resid.ptr if op.resid is not None else 0, ptr(go.mask),
                      self._pp(self.p_off[op.prelu]) if op.prelu else 0, rowtab, go.rows, op.x.cp, op.cout, op.out.cp,
-                     gx.wp, op.act_ch, CEPI_RESID if op.resid is not None else 0, 0, s)
+                     gx.wp, op.act_ch, CEPI_RESID if op.resid is not None else 0, 0, 0, s)
             else:
                 _, src, dst = op
                 call("vlg_upsample2x_fwd", src.ptr, dst.ptr, src.geo.b, src.geo.H, src.geo.W, src.cp, s)
@@ -323,7 +323,7 @@ class GridNetHIP:
                     taps = ptr(gx.down_taptabs) if op.stride == 2 else 0
                     call("vlg_conv3x3_dgrad", dout.ptr, self._pp(op.w_off), gin.ptr, op.x.ptr, ptr(gx.mask), slope,
                          self.da_part.data_ptr() + 4 * op.da_off if op.prelu else 0, taps, gx.rows if op.stride == 2 else 0, gx.rows, op.x.cp,
-                         op.out.cp, gx.wp, op.act_ch, epi, 0, s)
+                         op.out.cp, gx.wp, op.act_ch, epi, 0, 0, op.da_n, s)
                     op.x.grad_written = True
                 # the other branch of the residual sum receives the same gradient (gridnet.py:51-56)
                 if op.resid is not None:

@@ -55,10 +55,10 @@ SIGNATURES = {
     "vlg_ssim_loss": (I, [P, P, P, P, P, I, I, I, I, F, P]),
     "vlg_affine_nchw": (I, [P, P, I, I, L, P, P, P]),
     "vlg_prep_input": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
-    "vlg_conv3x3_fwd": (I, [P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, P, P]),
+    "vlg_conv3x3_fwd": (I, [P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, P, L, P]),
     "vlg_conv3x3_fwd_splits": (I, [L, I, I, I]),
     "vlg_conv3x3_dgrad_slabs": (I, [L, I]),
-    "vlg_conv3x3_dgrad": (I, [P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, P, P]),
+    "vlg_conv3x3_dgrad": (I, [P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, P, L, I, P]),
     "vlg_conv3x3_dgrad_splits": (I, [L, I, I]),
     "vlg_conv3x3_wgrad_slabs": (I, [L, I, I]),
     "vlg_conv3x3_wgrad": (I, [P, P, P, L, L, P, P, L, I, I, I, I, P]),

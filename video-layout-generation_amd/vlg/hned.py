@@ -80,6 +80,7 @@ class HNEDHIP:
                     for _, tin, tout, _, cout, _, _ in self.convs
                     if lib.vlg_conv3x3_fwd_splits(tout.geo.rows, tin.cp, cout, tout.cp) > 1] + [0])
         self.ws = torch.empty(need, dtype=torch.float32, device=device) if need else None
+        self.ws_n = need
         arr = ctypes.c_float * 3
         self._shift, self._scale = arr(*[m / 255.0 for m in BGR_MEAN]), arr(255.0, 255.0, 255.0)
 
@@ -130,7 +131,7 @@ class HNEDHIP:
                 done_pool.add(si)
             g = tout.geo
             call("vlg_conv3x3_fwd", tin.ptr, self._pp(key + ".weight"), self._pp(key + ".bias"), tout.ptr, 0, ptr(g.mask),
-                 self._pp("_zero") if relu else 0, 0, g.rows, tin.cp, cout, tout.cp, g.wp, tin.cp, 0, ptr(self.ws), s)
+                 self._pp("_zero") if relu else 0, 0, g.rows, tin.cp, cout, tout.cp, g.wp, tin.cp, 0, ptr(self.ws), self.ws_n, s)
         for k, (name, f) in enumerate(zip(SCORES, self.feats)):
             call("vlg_score1x1_relu", f.ptr, self._pp(name + ".weight"), self._pp(name + ".bias"), ptr(self.score[k]), b,
                  f.geo.H, f.geo.W, f.C, f.cp, s)

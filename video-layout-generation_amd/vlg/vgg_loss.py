@@ -91,6 +91,7 @@ class VggLossHIP:
                    [lib.vlg_conv3x3_dgrad_splits(op[2].geo.rows, op[2].cp, op[3].cp) * op[2].geo.rows * op[2].cp
                     for op in self.ops if op[0] == "conv" and lib.vlg_conv3x3_dgrad_splits(op[2].geo.rows, op[2].cp, op[3].cp) > 1] + [0])
         self.ws = torch.empty(need, dtype=torch.float32, device=device) if need else None
+        self.ws_n = need
 
     def reference_shapes(self):
         s = {}
@@ -130,7 +131,7 @@ class VggLossHIP:
                 _, key, tin, tout, ci, co, relu = op
                 g = tout.geo
                 call("vlg_conv3x3_fwd", tin.ptr, self._pp(key + ".weight"), self._pp(key + ".bias"), tout.ptr, 0, ptr(g.mask),
-                     self._pp("_zero") if relu else 0, 0, g.rows, tin.cp, co, tout.cp, g.wp, tin.cp, 0, ptr(self.ws), s)
+                     self._pp("_zero") if relu else 0, 0, g.rows, tin.cp, co, tout.cp, g.wp, tin.cp, 0, ptr(self.ws), self.ws_n, s)
 
     def loss_and_grad(self, output: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0, want_grad: bool = True):
         """Returns (loss[1] device tensor, d(grad_scale * loss)/d output as (b,3,H,W) or None)."""
@@ -154,7 +155,7 @@ class VggLossHIP:
                 g = tin.geo
                 call("vlg_conv3x3_dgrad", tout.grad.ptr, self._pp(key + ".weight"), tin.grad.ptr, tin.ptr, ptr(g.mask),
                      self._pp("_zero") if relu else 0, 0, 0, 0, g.rows, tin.cp, tout.cp, g.wp, tin.cp,
-                     CEPI_DPRELU if relu else 0, ptr(self.ws), s)
+                     CEPI_DPRELU if relu else 0, ptr(self.ws), self.ws_n, 0, s)
         dimg = torch.empty(b, 3, H, W, dtype=torch.float32, device=self.device)
         call("vlg_padded_to_nchw", self.x.grad.ptr, ptr(dimg), b, 3, H, W, self.x.cp, s)
         return self.loss, dimg
