@@ -97,3 +97,31 @@ def test_trainer_precision_knob(tmp_path, monkeypatch, precision, tol):
         assert torch.equal(again.engine.params, hip_tr.engine.params)
         assert torch.equal(again.engine.params_bf16, hip_tr.engine.params.to(torch.bfloat16))
         assert torch.equal(hip_tr.engine.params_bf16, hip_tr.engine.params.to(torch.bfloat16))
+
+
+def test_trainer_reads_the_reference_dataset_layout(tmp_path, monkeypatch):
+    """VLG_MODEL=gridnet with --train_dir / --val_dir pointing at frame triplets in the reference's Cityscapes layout
+    (src/folder.py:14-46): Trainer feeds them through vlg/cityscapes.py, the frozen HED net supplies the edge channels
+    (trainer.py:190-197) and an epoch trains; `VLG_WITH_VGG=1` adds the VGG19 term of CombinedLoss."""
+    from test_cityscapes_cpu import write_tree
+    root = tmp_path / "data"
+    write_tree(str(root / "train"), "aachen", 7, list(range(0, 16)), hw=(32, 32), seed=1)     # 9 triplets
+    write_tree(str(root / "val"), "bonn", 2, list(range(0, 10)), hw=(32, 32), seed=2)         # 3 triplets
+    (tmp_path / "src").mkdir()
+    monkeypatch.chdir(tmp_path / "src")
+    monkeypatch.setenv("VLG_MODEL", "gridnet")
+    monkeypatch.setenv("VLG_IMG_SIZE", "32")
+    monkeypatch.setenv("VLG_WITH_VGG", "1")
+    from trainer import Trainer
+    random.seed(1024)
+    args = reference_args(tmp_path / "exp", batch_size=2, epochs=2, print_freq=1, lr=2e-3,
+                          train_dir=str(root / "train"), val_dir=str(root / "val"))
+    tr = Trainer(args)
+    assert tr.image_mode and tr.engine.on_disk and tr.engine.engine.hed is not None and tr.engine.engine.vgg is not None
+    assert len(tr.train_loader) == 4 and len(tr.val_loader) == 1
+    vals = []
+    for epoch in range(args.epochs):
+        tr.set_epoch(epoch)
+        tr.train()
+        vals.append(tr.validate()["loss"])
+    assert all(v == v and v > 0 for v in vals) and vals[1] < vals[0], vals

@@ -15,7 +15,9 @@ byte-for-byte unchanged:  VLG_FRAMES (T, 16), VLG_SLOTS (N, 64), VLG_DMODEL (d, 
 VLG_LAYERS (4), VLG_TRAIN_CLIPS (1024), VLG_VAL_CLIPS (256), VLG_VARIABLE_N (0), VLG_PRECISION (fp32 | fp32x3 | bf16 |
 bf16_mfma: projection arithmetic / activation storage, vlg/engine.py).
 
-VLG_MODEL=gridnet switches the step to the reference's OWN model and losses (vlg/image_engine.py:
+VLG_MODEL=gridnet switches the step to the reference's OWN model and losses (vlg/image_engine.py;
+VLG_WITH_HED / VLG_WITH_VGG = 1 add the frozen edge net and the VGG19 term, VLG_HED_CKPT / VLG_VGG_CKPT their weights;
+--train_dir / --val_dir in the reference's Cityscapes layout are read by vlg/cityscapes.py, else frames are synthetic:
 --arch GridNet|CoordGridNet on the conv3x3 MFMA kernels, 40 L1 + 20 (GradientLoss + SSIM) + 10 CE, reference
 src/trainer.py:193-258) on synthetic frame triplets of VLG_IMG_SIZE (256) pixels; the default (layout) is the
 token step BASELINE.json's metric is quoted on.
@@ -132,12 +134,32 @@ class _ImageModel:
     def __init__(self, args, batch: int):
         from vlg.image_engine import IMAGE_KEYS, ImageEngine
         size = _knob(args, "img_size", "VLG_IMG_SIZE", 256)
-        self.keys = IMAGE_KEYS
         self.size = size
         self.device = torch.device("cuda", int(args.rank))
         arch = args.arch if args.arch in ("GridNet", "CoordGridNet") else "CoordGridNet"
+        from vlg.cityscapes import is_dataset_root
+        self.on_disk = is_dataset_root(getattr(args, "train_dir", None))        # reference layout (src/folder.py:14-46)
+        # the frozen edge net feeds two of the ten input channels (trainer.py:190-197): needed as soon as frames come
+        # from files; the VGG19 term of CombinedLoss (loss.py:61-62) is opt-in - neither net's trained weights ship
+        # with the reference (trainer.py:97 is an author-local path, vgg19(pretrained=True) a download)
+        with_hed = self.on_disk or bool(_knob(args, "with_hed", "VLG_WITH_HED", 0))
+        with_vgg = bool(_knob(args, "with_vgg", "VLG_WITH_VGG", 0))
+        self.keys = tuple(k for k in IMAGE_KEYS if not (with_hed and k in ("e1", "e2")))   # HED makes the edge maps itself
         self.engine = ImageEngine(batch, size, size, self.device, arch=arch, lr=float(getattr(args, "lr", ADAM_LR)),
-                                  beta1=float(getattr(args, "beta1", ADAM_BETA1)))
+                                  beta1=float(getattr(args, "beta1", ADAM_BETA1)), with_hed=with_hed, with_vgg=with_vgg)
+        for net, env in ((self.engine.hed, "VLG_HED_CKPT"), (self.engine.vgg, "VLG_VGG_CKPT")):
+            if net is None:
+                continue
+            path = os.environ.get(env)
+            if path:                                   # a state_dict in the reference's / torchvision's key format
+                sd_ = torch.load(path, map_location="cpu", weights_only=True)
+                net.load_state_dict(sd_.get("state_dict", sd_) if isinstance(sd_, dict) else sd_)
+            else:                                      # torch's default conv initialisation, same seed on every rank
+                gi = torch.Generator().manual_seed(int(getattr(args, "seed", SEED)) + 17)
+                shp_ = net.reference_shapes()
+                net.load_state_dict({k: (torch.rand(v, generator=gi) * 2 - 1) / float(max(1, (v[1] * v[2] * v[3]) if len(v) == 4 else 64)) ** 0.5
+                                     for k, v in shp_.items()})
+                args.logger.info("%s not set: %s runs with randomly initialised frozen weights" % (env, type(net).__name__))
         # torch's default initialisers for Conv2d (U(+-1/sqrt(fan_in)) for weight and bias) and PReLU (0.25), from one
         # generator seeded like every rank's (main.py:57-60) so replicas start identical without a broadcast
         g = torch.Generator().manual_seed(int(getattr(args, "seed", SEED)))
@@ -236,6 +258,14 @@ class Trainer:
         n_train = _knob(args, "train_clips", "VLG_TRAIN_CLIPS", 1024)
         n_val = _knob(args, "val_clips", "VLG_VAL_CLIPS", 256)
         common = dict(batch=self.cfg.B, rank=int(args.rank), world=self.world, seed=seed)
+        if self.image_mode and self.engine.on_disk:
+            # the reference's own data: frame triplets from <train_dir>/{deeplab256_label,leftImg256}/<city>/ (folder.py)
+            from vlg.cityscapes import TripletFolder, TripletLoader
+            val_dir = getattr(args, "val_dir", None) or args.train_dir
+            self.train_loader = TripletLoader(TripletFolder(args.train_dir), shuffle=True, device=self.device, **common)
+            self.val_loader = TripletLoader(TripletFolder(val_dir), shuffle=False, device=self.device, **common)
+            args.logger.debug("Finish init trainer")
+            return
         if self.image_mode:
             from vlg.image_engine import synthetic_frames
             sz = self.engine.size
