@@ -21,8 +21,6 @@ from __future__ import annotations
 import os
 import threading
 import queue
-from itertools import groupby
-from operator import itemgetter
 from typing import Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -40,26 +38,38 @@ def is_dataset_root(path: Optional[str]) -> bool:
         os.path.isdir(os.path.join(os.path.expanduser(path), IMG_DIR))
 
 
+def _consecutive_runs(numbers: List[int]) -> List[Tuple[int, int]]:
+    """(first, last) of every maximal run of consecutive integers in a sorted list."""
+    runs: List[Tuple[int, int]] = []
+    for n in numbers:
+        if runs and n == runs[-1][1] + 1:
+            runs[-1] = (runs[-1][0], n)
+        elif not runs or n != runs[-1][1]:
+            runs.append((n, n))
+    return runs
+
+
 def make_dataset(root: str) -> List[Tuple[List[str], List[str]]]:
-    """[(three segmentation paths, three frame paths)] - reference src/folder.py:14-46."""
+    """[(three segmentation paths, three frame paths)], the enumeration of reference src/folder.py:14-46."""
     root = os.path.expanduser(root)
-    seg_sub, img_sub = os.path.join(root, SEG_DIR), os.path.join(root, IMG_DIR)
-    out: List[Tuple[List[str], List[str]]] = []
-    for city in sorted(os.listdir(seg_sub)):
-        city_dir = os.path.join(seg_sub, city)
-        if not os.path.isdir(city_dir):
+    seg_root, img_root = os.path.join(root, SEG_DIR), os.path.join(root, IMG_DIR)
+    samples: List[Tuple[List[str], List[str]]] = []
+    for city in sorted(os.listdir(seg_root)):
+        if not os.path.isdir(os.path.join(seg_root, city)):
             continue
-        files = [f for f in os.listdir(city_dir) if f.endswith(".png")]
-        for idx in sorted({int(f.split("_")[1]) for f in files}):
-            stem = city + "_" + str(idx).zfill(6)
-            frames = sorted(int(f.split("_")[2]) for f in files if f.startswith(stem))
-            for _, grp in groupby(enumerate(frames), lambda t: t[0] - t[1]):      # runs of consecutive frame numbers
-                run = list(map(itemgetter(1), grp))
-                for i in range(run[0], run[-1] - 6):                                # folder.py:33-34, bound kept
-                    names = [os.path.join(city, "%s_%s" % (stem, str(i + 3 * j).zfill(6))) for j in range(3)]
-                    out.append(([os.path.join(seg_sub, n + SEG_SUFFIX) for n in names],
-                                [os.path.join(img_sub, n + IMG_SUFFIX) for n in names]))
-    return out
+        by_snippet: Dict[int, List[int]] = {}
+        for name in os.listdir(os.path.join(seg_root, city)):
+            if name.endswith(".png"):
+                parts = name.split("_")                                    # <city>_<snippet>_<frame>_gtFine_myseg_id.png
+                by_snippet.setdefault(int(parts[1]), []).append(int(parts[2]))
+        for snippet in sorted(by_snippet):
+            stem = "%s_%06d" % (city, snippet)
+            for first, last in _consecutive_runs(sorted(by_snippet[snippet])):
+                for i in range(first, last - 6):                            # the reference's bound (folder.py:33-34), kept
+                    names = [os.path.join(city, "%s_%06d" % (stem, i + 3 * j)) for j in range(3)]
+                    samples.append(([os.path.join(seg_root, n + SEG_SUFFIX) for n in names],
+                                    [os.path.join(img_root, n + IMG_SUFFIX) for n in names]))
+    return samples
 
 
 def _load_rgb(path: str) -> torch.Tensor:
