@@ -205,6 +205,14 @@ int vlg_prep_input(const float* e1, const float* seg1, const float* frame1,
                    float* x10, float* frame3_out, int64_t* seg3_out,
                    int b, int H, int W, int flip, void* stream);
 
+/* Autoregressive rollout, reference src/trainer.py:453-476 (8 steps from two frames + two segmentation maps).
+ *   vlg_argmax_nchw    out[b,1,hw] = float(argmax over C of logits[b,C,hw]), first maximum wins     trainer.py:467
+ *   vlg_rollout_input  x10 = cat[e_a, seg_a, img_a, img_b, seg_b, e_b] (frames already normalised): trainer.py:461 with
+ *                      the two edge channels the 10-channel net was trained with (trainer.py:197) */
+int vlg_argmax_nchw(const float* logits, float* out, int b, int C, int64_t hw, void* stream);
+int vlg_rollout_input(const float* e_a, const float* seg_a, const float* img_a, const float* img_b,
+                      const float* seg_b, const float* e_b, float* x10, int b, int64_t hw, void* stream);
+
 /* ------------------------------------------------- GridNet convolution path (reference-real)
  * The reference's trainable model (CoordGridNet / GridNet, reference src/models/gridnet.py:7-114) is built
  * from three blocks (reference src/models/modules.py:5-58): PReLU -> conv3x3 -> PReLU -> conv3x3, the first

@@ -120,41 +120,64 @@ def _conv(p, key, x, stride=1):
     return F.conv2d(x, p[key + ".weight"], p[key + ".bias"], stride=stride, padding=1)
 
 
-def _block(p, name, kind, x):
+class Branches:
+    """Optional record / override of which side of its kink every PReLU input fell on.
+
+    `record` (dict) receives {PReLU key: the input tensor}.  `positive` ({PReLU key: bool tensor}) REPLACES the
+    test x > 0 of that PReLU: y = x where positive, slope * x elsewhere, so autograd's derivatives follow the
+    given pattern.  Used to compare backward passes of two fp32 implementations exactly: given the SAME branch
+    pattern a PReLU network's backward is a smooth function of everything else, so the 1e-4 bound applies to every
+    gradient; the pattern itself is compared separately (it may differ only where |x| sits inside the rounding band
+    of the forward pass).  With neither, F.prelu runs untouched (the path pinned bit for bit to the reference)."""
+
+    def __init__(self, positive=None, record=None):
+        self.positive, self.record = positive, record
+
+
+def _prelu(p, key, x, br):
+    if br is not None and br.record is not None:
+        br.record[key] = x.detach()
+    if br is None or br.positive is None:
+        return F.prelu(x, p[key])
+    return torch.where(br.positive[key], x, p[key] * x)
+
+
+def _block(p, name, kind, x, br=None):
     if kind == "up":
         x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)         # modules.py:50
-        x = _conv(p, name + ".up.2", F.prelu(x, p[name + ".up.1.weight"]))
-        return _conv(p, name + ".up.4", F.prelu(x, p[name + ".up.3.weight"]))
-    x = _conv(p, name + ".conv.1", F.prelu(x, p[name + ".conv.0.weight"]), stride=2 if kind == "down" else 1)
-    return _conv(p, name + ".conv.3", F.prelu(x, p[name + ".conv.2.weight"]))
+        x = _conv(p, name + ".up.2", _prelu(p, name + ".up.1.weight", x, br))
+        return _conv(p, name + ".up.4", _prelu(p, name + ".up.3.weight", x, br))
+    x = _conv(p, name + ".conv.1", _prelu(p, name + ".conv.0.weight", x, br), stride=2 if kind == "down" else 1)
+    return _conv(p, name + ".conv.3", _prelu(p, name + ".conv.2.weight", x, br))
 
 
-def forward(p: Dict[str, torch.Tensor], x: torch.Tensor, coord: bool = False, n_col: int = 6):
+def forward(p: Dict[str, torch.Tensor], x: torch.Tensor, coord: bool = False, n_col: int = 6, branches: "Branches" = None):
     """GridNet.forward (gridnet.py:43-58) / CoordGridNet.forward (:99-114).  Returns (seg, img)."""
+    br = branches
     if coord:
         xc = add_coords(x)
-        h = F.prelu(_conv(p, "lateral_in.conv.0.conv", xc), p["lateral_in.conv.1.weight"])
+        h = _prelu(p, "lateral_in.conv.1.weight", _conv(p, "lateral_in.conv.0.conv", xc), br)
         x0 = _conv(p, "lateral_in.conv.2.conv", add_coords(h)) + _conv(p, "lateral_in.conv2.conv", xc)
     else:
-        x0 = _block(p, "lateral_in", "lateral", x) + _conv(p, "lateral_in.conv2", x)
-    x1 = _block(p, "down_00", "down", x0)
-    x2 = _block(p, "down_10", "down", x1)
+        x0 = _block(p, "lateral_in", "lateral", x, br) + _conv(p, "lateral_in.conv2", x)
+    x1 = _block(p, "down_00", "down", x0, br)
+    x2 = _block(p, "down_10", "down", x1, br)
     for i in range(1, n_col):
         if i < n_col / 2:
-            x0 = _block(p, "lateral_0%d" % (i - 1), "lateral", x0)
-            x1 = _block(p, "down_0%d" % i, "down", x0) + _block(p, "lateral_1%d" % (i - 1), "lateral", x1)
-            x2 = _block(p, "down_1%d" % i, "down", x1) + _block(p, "lateral_2%d" % (i - 1), "lateral", x2)
+            x0 = _block(p, "lateral_0%d" % (i - 1), "lateral", x0, br)
+            x1 = _block(p, "down_0%d" % i, "down", x0, br) + _block(p, "lateral_1%d" % (i - 1), "lateral", x1, br)
+            x2 = _block(p, "down_1%d" % i, "down", x1, br) + _block(p, "lateral_2%d" % (i - 1), "lateral", x2, br)
         else:
-            x2 = _block(p, "lateral_2%d" % (i - 1), "lateral", x2)
-            x1 = _block(p, "up_1%d" % i, "up", x2) + _block(p, "lateral_1%d" % (i - 1), "lateral", x1)
-            x0 = _block(p, "up_0%d" % i, "up", x1) + _block(p, "lateral_0%d" % (i - 1), "lateral", x0)
-    return _block(p, "lateral_out_seg", "lateral", x0), _block(p, "lateral_out_img", "lateral", x0)
+            x2 = _block(p, "lateral_2%d" % (i - 1), "lateral", x2, br)
+            x1 = _block(p, "up_1%d" % i, "up", x2, br) + _block(p, "lateral_1%d" % (i - 1), "lateral", x1, br)
+            x0 = _block(p, "up_0%d" % i, "up", x1, br) + _block(p, "lateral_0%d" % (i - 1), "lateral", x0, br)
+    return _block(p, "lateral_out_seg", "lateral", x0, br), _block(p, "lateral_out_img", "lateral", x0, br)
 
 
-def forward_backward(p, x, r_seg, r_img, coord=False):
+def forward_backward(p, x, r_seg, r_img, coord=False, branches: "Branches" = None):
     """loss = sum(seg * r_seg) + sum(img * r_img); returns (seg, img, {key: grad}, dx)."""
     q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
     xin = x.detach().clone().requires_grad_(True)
-    seg, img = forward(q, xin, coord)
+    seg, img = forward(q, xin, coord, branches=branches)
     ((seg * r_seg).sum() + (img * r_img).sum()).backward()
     return seg.detach(), img.detach(), {k: v.grad for k, v in q.items()}, xin.grad

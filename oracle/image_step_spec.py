@@ -32,7 +32,7 @@ def ssim_loss(x, y):                                        # reference src/loss
     return sum(one(x[:, i], y[:, i]) for i in range(x.size()[1]))
 
 
-def step_losses(p, batch, coord, flip=False, vgg_params=None):
+def step_losses(p, batch, coord, flip=False, vgg_params=None, branches=None):
     img_mean = torch.tensor([0.485, 0.456, 0.406])[None, :, None, None]        # trainer.py:123
     img_std = torch.tensor([0.229, 0.224, 0.225])[None, :, None, None]         # trainer.py:122
     mean_arr = torch.tensor([-0.03, -0.088, -0.188])[None, :, None, None]      # trainer.py:120
@@ -44,7 +44,7 @@ def step_losses(p, batch, coord, flip=False, vgg_params=None):
     seg3 = batch["seg3"]
     if flip:                                                                    # :200-206
         x, f3, seg3 = torch.flip(x, [3]), torch.flip(f3, [3]), torch.flip(seg3, [2])
-    seg, img = G.forward(p, x, coord)                                           # :209
+    seg, img = G.forward(p, x, coord, branches=branches)                        # :209
     img = (img - mean_arr) / std_arr                                            # :212
     l1 = F.l1_loss(img, f3)                                                     # :248 (x40 below)
     gd, ss = gradient_loss(img, f3), ssim_loss(img, f3)                         # :249 CombinedLoss without VGG
@@ -56,8 +56,9 @@ def step_losses(p, batch, coord, flip=False, vgg_params=None):
     return l1, gd, ss, ce, 40 * l1 + 20 * style + 10 * ce                      # :251
 
 
-def loss_and_grads(p, batch, coord, flip=False, vgg_params=None):
+def loss_and_grads(p, batch, coord, flip=False, vgg_params=None, branches=None):
+    """`branches` (oracle.gridnet_spec.Branches) pins / records the PReLU branch pattern, see there."""
     q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    parts = step_losses(q, batch, coord, flip, vgg_params)
+    parts = step_losses(q, batch, coord, flip, vgg_params, branches)
     parts[4].backward()
     return [float(v.detach()) for v in parts], {k: v.grad for k, v in q.items()}

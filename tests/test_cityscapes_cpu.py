@@ -77,8 +77,21 @@ def test_segmentation_is_resized_nearest_to_the_frame(tmp_path):
     data = write_tree(root, "ulm", 3, list(range(0, 8)), hw=(8, 12), seg_hw=(16, 24))      # label maps at twice the size
     it = TripletFolder(root)[0]
     assert tuple(it["seg1"].shape) == (1, 8, 12) and tuple(it["seg3"].shape) == (8, 12)
-    want = np.asarray(Image.fromarray(data[0][1], "L").resize((12, 8), Image.NEAREST))
+    # cv2.INTER_NEAREST's index rule (folder.py:133): destination (y, x) <- source (floor(y * 2), floor(x * 2)) for a 2x
+    # downscale, i.e. the even rows / columns - NOT PIL's centre sampling, which would take the odd ones
+    want = data[0][1][0::2, 0::2]
     assert torch.equal(it["seg1"][0], torch.from_numpy(want.copy()).float())
+    assert not np.array_equal(want, np.asarray(Image.fromarray(data[0][1], "L").resize((12, 8), Image.NEAREST)))
+
+
+def test_nearest_resize_follows_the_cv2_index_rule():
+    from vlg.cityscapes import resize_nearest_cv2
+    a = np.arange(7 * 5, dtype=np.uint8).reshape(7, 5)
+    up = resize_nearest_cv2(a, (14, 10))                         # upscale 2x: every source pixel twice
+    assert np.array_equal(up, np.repeat(np.repeat(a, 2, 0), 2, 1))
+    down = resize_nearest_cv2(np.arange(64, dtype=np.uint8).reshape(8, 8), (3, 3))   # ratio 8/3: rows floor(0, 2.67, 5.33)
+    assert np.array_equal(down, np.arange(64).reshape(8, 8)[[0, 2, 5]][:, [0, 2, 5]])
+    assert np.array_equal(resize_nearest_cv2(a, a.shape), a)
 
 
 def test_loader_shards_like_the_clip_loader(tmp_path):

@@ -31,6 +31,41 @@ def kink_tolerant(got, want, what):
     assert float((got - want).norm()) <= 5e-3 * max(float(want.norm()), 1e-12), what
 
 
+def branch_pattern(net, p, x, coord, band=1e-5):
+    """The PReLU branch pattern of the HIP forward ({key: x > 0}), checked against the CPU restatement's own: the two
+    may disagree ONLY on elements whose pre-activation lies within `band` x (tensor scale) of the kink, i.e. inside the
+    forward pass's fp32 rounding band - anything else is a forward error.  Returns (pattern, number of disagreements)."""
+    positive = {k: (v > 0).cpu() for k, v in net.prelu_inputs().items()}
+    rec = {}
+    with torch.no_grad():
+        G.forward(p, x, coord, branches=G.Branches(record=rec))
+    assert set(rec) == set(positive)
+    flips = 0
+    for k, v in rec.items():
+        diff = (v > 0) != positive[k]
+        if bool(diff.any()):
+            worst = float(v[diff].abs().max())
+            assert worst <= band * float(v.abs().max()), ("branch of %s differs %.3e away from the kink" % (k, worst))
+            flips += int(diff.sum())
+    return positive, flips
+
+
+def strict_given_branches(net, dx, p, x, r_seg, r_img, coord, tol=1e-4):
+    """REAL slopes, strict bound: the backward pass of a PReLU network is smooth once every element's branch is fixed,
+    so with the CPU restatement evaluated (in fp64) on the branch pattern the HIP forward actually took, every
+    gradient - dx, every weight / bias tensor, every slope gradient - must agree to `tol`; the pattern itself is held
+    to the restatement's by branch_pattern().  Together with the 1e-4 forward check this is parity with no
+    kink allowance: a sign, indexing or slope-selection slip in the dPReLU epilogue, the act_ch cut-off or the slope
+    partials fails here."""
+    positive, flips = branch_pattern(net, p, x, coord)
+    p64 = {k: v.double() for k, v in p.items()}
+    _, _, grads_w, dx_w = G.forward_backward(p64, x.double(), r_seg.double(), r_img.double(), coord,
+                                             branches=G.Branches(positive=positive))
+    rel_close(dx, dx_w, tol=tol, what="dx (branches pinned)")
+    check_grads(net.named_grads(), grads_w, True, tol=tol)
+    return flips
+
+
 def check_grads(grads, want, linear, tol=1e-4):
     """All parameter gradients.  Tensors: rel_close (smooth net) / kink_tolerant (real slopes).  PReLU-slope
     gradients are single numbers - cancelling sums over every activation of a layer - so they are compared on
@@ -73,6 +108,9 @@ def test_gridnet_small_matches_reference_everywhere(dev, linear):
     grads = net.named_grads()
     assert set(tag + "grad:" + k for k in grads) == set(k for k in z.files if k.startswith(tag + "grad:"))
     check_grads(grads, {k: torch.from_numpy(z[tag + "grad:" + k]) for k in grads}, linear)
+    if not linear:
+        p = G.test_params(G.param_shapes(10, (8, 16, 24)), seed=1)
+        strict_given_branches(net, dx, p, torch.from_numpy(z["x"]), torch.from_numpy(z["r_seg"]), torch.from_numpy(z["r_img"]), False)
 
 
 @pytest.mark.parametrize("linear", [False, True])
@@ -92,6 +130,8 @@ def test_gridnet_real_widths_64(dev, linear):
     want = {f[len(tag) + 5:]: torch.from_numpy(z[f]) for f in z.files if f.startswith(tag + "grad:")}
     want.update({str(n): torch.tensor([float(v)]) for n, v in zip(z["prelu_names"], z[tag + "prelu_grads"])})
     check_grads(grads, want, linear)
+    if not linear:
+        strict_given_branches(net, dx, G.test_params(G.param_shapes(10), seed=2), x, r_seg, r_img, False)
     order = list(G.param_shapes(10).keys())
     for k, w in zip(order, z[tag + "grad_abs_sums"]):
         if grads[k].numel() > 1:                                  # every other tensor: |grad| sum (slopes: above)
@@ -118,6 +158,9 @@ def test_coordgridnet_256(dev, linear):
     check(dx[:, :, -16:, -16:], torch.from_numpy(z[tag + "dx_crop"]), what="dx crop")
     check_grads(net.named_grads(), {f[len(tag) + 5:]: torch.from_numpy(z[f]) for f in z.files if f.startswith(tag + "grad:")},
                 linear, tol=2e-4)
+    if not linear:
+        strict_given_branches(net, dx, G.test_params(G.param_shapes(10, (8, 16, 24), coord=True), seed=3), x, r_seg, r_img,
+                              True, tol=2e-4)
 
 
 @pytest.mark.parametrize("linear", [False, True])
@@ -139,6 +182,8 @@ def test_against_cpu_restatement_other_shapes(dev, b, H, W, filters, linear):
     check = (lambda a, w, what: rel_close(a, w, tol=2e-4, what=what)) if linear else kink_tolerant
     check(dx, dx_w, what="dx")
     check_grads(net.named_grads(), grads_w, linear, tol=2e-4)
+    if not linear:
+        strict_given_branches(net, dx, p, x, r_seg, r_img, False, tol=2e-4)
     # halo stays exactly zero after forward + backward (the convolutions rely on it)
     for t in net.tensors:
         v = t.buf[t.geo.guard * t.cp:(t.geo.guard + t.geo.rows) * t.cp].view(t.geo.b, t.geo.H + 2, t.geo.W + 2, t.cp)

@@ -30,6 +30,32 @@ def test_reference_step_body(dev, arch, linear, flip):
         assert abs(float(got[i]) - parts[i]) <= 1e-4 * abs(parts[i]), (name, float(got[i]), parts[i])
     assert abs(float(eng.total()) - parts[4]) <= 1e-4 * abs(parts[4])
     check_grads(eng.net.named_grads(), grads, linear, tol=3e-4)
+    if not linear:
+        strict_step_gradients(eng, p, batch, coord)
+
+
+def strict_step_gradients(eng, p, batch, coord, tol=3e-4):
+    """REAL slopes, no kink allowance.  The step's gradient is discontinuous in two places: the PReLU branches and the
+    losses' own kinks (|a - b| of L1, ||da| - |db|| of GradientLoss, SSIM's clamp, reference src/loss.py:20-25,68-91),
+    so two fp32 forwards that agree to 2e-7 can still take different sides on a few pixels.  Each smooth piece is
+    therefore compared AT THE SAME POINT: (1) the loss gradients the kernels produced vs autograd of the restated
+    losses evaluated on the HIP outputs; (2) the network backward vs the restatement on the branch pattern the HIP
+    forward took (test_hip_gridnet.branch_pattern also bounds where the patterns may differ), fed those gradients."""
+    import torch.nn.functional as F
+    from test_hip_gridnet import branch_pattern, rel_close
+    std_arr = torch.tensor([0.448, 0.448, 0.450])[None, :, None, None]          # trainer.py:121
+    a = eng.img.cpu().requires_grad_(True)
+    sgm = eng.seg.cpu().requires_grad_(True)
+    f3, seg3 = eng.f3.cpu(), eng.seg3.cpu()
+    (40 * F.l1_loss(a, f3) + 20 * (S.gradient_loss(a, f3) + S.ssim_loss(a, f3)) + 10 * F.cross_entropy(sgm, seg3)).backward()
+    dimg_raw = a.grad / std_arr                                                  # through img = (img - mean) / std, :212
+    rel_close(eng.dseg, sgm.grad, tol=1e-4, what="d loss / d seg")
+    rel_close(eng.dtmp, dimg_raw, tol=1e-4, what="d loss / d img")
+    positive, _ = branch_pattern(eng.net, p, eng.x10.cpu(), coord)
+    q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    seg_o, img_o = G.forward(q, eng.x10.cpu(), coord, branches=G.Branches(positive=positive))
+    ((seg_o * sgm.grad).sum() + (img_o * dimg_raw).sum()).backward()
+    check_grads(eng.net.named_grads(), {k: v.grad for k, v in q.items()}, True, tol=tol)
 
 
 def test_adam_steps_reduce_the_loss(dev):

@@ -125,3 +125,58 @@ def test_trainer_reads_the_reference_dataset_layout(tmp_path, monkeypatch):
         tr.train()
         vals.append(tr.validate()["loss"])
     assert all(v == v and v > 0 for v in vals) and vals[1] < vals[0], vals
+
+
+def test_gridnet_mode_loads_a_reference_checkpoint(tmp_path, monkeypatch):
+    """--ckpt as reference src/trainer.py:85-92 reads it: {'gridnet': state_dict, 'optimizer': torch.optim.Adam
+    state_dict over model.parameters()}.  Built here with torch itself over parameters in the reference's registration
+    order; the Trainer must continue EXACTLY where that optimiser stood: one more step on the HIP engine equals one more
+    torch step fed the HIP gradients.  The checkpoint the Trainer writes loads back into a torch Adam."""
+    from oracle import gridnet_spec as G
+    (tmp_path / "src").mkdir()
+    monkeypatch.chdir(tmp_path / "src")
+    monkeypatch.setenv("VLG_MODEL", "gridnet")
+    monkeypatch.setenv("VLG_IMG_SIZE", "32")
+    shapes = G.param_shapes(10, coord=True)
+    p0 = G.test_params(shapes, seed=8)
+    tp = [torch.nn.Parameter(p0[k].clone()) for k in shapes]              # reference order = parameters() order
+    opt = torch.optim.Adam(tp, lr=2e-3, betas=(0.5, 0.999))
+    g = torch.Generator().manual_seed(1)
+    for _ in range(2):
+        for q in tp:
+            q.grad = torch.randn(q.shape, generator=g) * 0.01
+        opt.step()
+    weights = {k: q.detach().clone() for k, q in zip(shapes, tp)}
+    torch.save({"epoch": 3, "arch": "CoordGridNet", "gridnet": weights, "optimizer": opt.state_dict()}, str(tmp_path / "ref.pth"))
+    from trainer import Trainer
+    random.seed(1024)
+    tr = Trainer(reference_args(tmp_path / "exp", batch_size=2, epochs=1, print_freq=1, train_clips=4, val_clips=2,
+                                lr=2e-3, ckpt=str(tmp_path / "ref.pth")))
+    eng = tr.engine.engine
+    sd = eng.state_dict()
+    assert all(torch.equal(sd[k], weights[k]) for k in shapes)
+    assert eng.step_count == 2
+    m = eng.net.unpack(eng.exp_avg)
+    st = opt.state_dict()["state"]
+    assert all(torch.equal(m[k], st[i]["exp_avg"]) for i, k in enumerate(shapes))
+    # one step on the HIP engine == one torch.optim step on the same gradients
+    batch = {k: v.to(tr.device) for k, v in next(iter(tr.train_loader)).items()}
+    eng.train_step(batch)
+    grads = eng.net.named_grads()
+    for k, q in zip(shapes, tp):
+        q.grad = grads[k].clone()
+    opt.step()
+    after = eng.state_dict()
+    for k, q in zip(shapes, tp):
+        assert torch.allclose(after[k], q.detach(), rtol=1e-5, atol=1e-7), k
+    # what the Trainer saves is a torch.optim.Adam state_dict again
+    tr.save_checkpoint({"loss": 0.0})
+    ck = torch.load("../checkpoint/latest.pth", weights_only=True)
+    opt2 = torch.optim.Adam([torch.nn.Parameter(torch.zeros(s)) for s in shapes.values()], lr=1.0)
+    opt2.load_state_dict(ck["optimizer"])
+    assert int(opt2.state_dict()["state"][0]["step"]) == 3 and opt2.state_dict()["param_groups"][0]["betas"][0] == 0.5
+    # a state of the wrong architecture is refused with a clear message, not a KeyError
+    bad = dict(ck["optimizer"])
+    bad["param_groups"] = [dict(bad["param_groups"][0], params=list(range(5)))]
+    with pytest.raises(ValueError):
+        eng.load_optimizer(bad)

@@ -359,3 +359,57 @@ extern "C" int vlg_prep_input(const float* e1, const float* seg1, const float* f
                        frame1, frame2, seg2, e2, frame3, seg3, x10, frame3_out, seg3_out, b, H, W, flip);
     return vlg_last_error();
 }
+
+// ---- autoregressive rollout (reference src/trainer.py:453-476)
+// seg_next = torch.argmax(seg_next, dim=1).unsqueeze_(1).float()      trainer.py:467   (first maximum wins, as torch)
+__global__ __launch_bounds__(IMG_BLOCK) void argmax_nchw_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                               int64_t n, int C, int64_t hw) {
+    for (int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IMG_BLOCK) {
+        const int64_t b = i / hw, r = i - b * hw;
+        const float* p = logits + b * C * hw + r;
+        float best = p[0];
+        int arg = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = p[c * hw];
+            if (v > best) { best = v; arg = c; }
+        }
+        out[i] = (float)arg;
+    }
+}
+
+extern "C" int vlg_argmax_nchw(const float* logits, float* out, int b, int C, int64_t hw, void* stream) {
+    if (b < 1 || C < 1 || hw < 1) return VLG_ERR_SHAPE;
+    const int64_t n = (int64_t)b * hw;
+    hipLaunchKernelGGL(argmax_nchw_kernel, dim3(img_blocks(n)), dim3(IMG_BLOCK), 0, (hipStream_t)stream, logits, out, n, C, hw);
+    return vlg_last_error();
+}
+
+// x = cat[e_a, seg_a, img_a, img_b, seg_b, e_b] of frames that are ALREADY normalised: the rollout's input
+// (trainer.py:461 with the channel order of the training input, trainer.py:197 - Appendix A-10 repaired)
+__global__ __launch_bounds__(IMG_BLOCK) void rollout_input_kernel(const float* __restrict__ ea, const float* __restrict__ sa,
+                                                                 const float* __restrict__ ia, const float* __restrict__ ib,
+                                                                 const float* __restrict__ sb, const float* __restrict__ eb,
+                                                                 float* __restrict__ x10, int64_t n, int64_t hw) {
+    for (int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IMG_BLOCK) {
+        const int64_t b = i / hw, r = i - b * hw;
+        float* xo = x10 + b * 10 * hw + r;
+        xo[0] = ea[i];
+        xo[hw] = sa[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xo[(2 + c) * hw] = ia[(b * 3 + c) * hw + r];
+            xo[(5 + c) * hw] = ib[(b * 3 + c) * hw + r];
+        }
+        xo[8 * hw] = sb[i];
+        xo[9 * hw] = eb[i];
+    }
+}
+
+extern "C" int vlg_rollout_input(const float* e_a, const float* seg_a, const float* img_a, const float* img_b,
+                                 const float* seg_b, const float* e_b, float* x10, int b, int64_t hw, void* stream) {
+    if (b < 1 || hw < 1) return VLG_ERR_SHAPE;
+    const int64_t n = (int64_t)b * hw;
+    hipLaunchKernelGGL(rollout_input_kernel, dim3(img_blocks(n)), dim3(IMG_BLOCK), 0, (hipStream_t)stream, e_a, seg_a, img_a,
+                       img_b, seg_b, e_b, x10, n, hw);
+    return vlg_last_error();
+}

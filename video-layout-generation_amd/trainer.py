@@ -128,6 +128,30 @@ def get_layout_engine(args, cfg: Optional[LayoutConfig] = None, engine_factory: 
 get_gridnet = get_layout_engine     # reference name (src/trainer.py:81)
 
 
+def _load_frozen(net, env: str, args) -> None:
+    """Weights of a frozen net (HED / VGG19).  `env` names a state_dict file in the reference's / torchvision's key
+    format; the authors' HED checkpoint keeps it under 'generator' (reference src/trainer.py:99), other tools under
+    'state_dict'.  Without a file the net gets torch's default conv initialisation from the shared seed (identical on
+    every rank) - announced at WARNING level, because the edge maps / perceptual term then mean nothing."""
+    path = os.environ.get(env)
+    if path:
+        sd_ = torch.load(path, map_location="cpu", weights_only=True)
+        for key in ("generator", "state_dict"):
+            if isinstance(sd_, dict) and key in sd_ and isinstance(sd_[key], dict):
+                sd_ = sd_[key]
+                break
+        net.load_state_dict(sd_)
+        args.logger.info("%s: loaded %s" % (type(net).__name__, path))
+        return
+    gi = torch.Generator().manual_seed(int(getattr(args, "seed", SEED)) + 17)
+    shp_ = net.reference_shapes()
+    net.load_state_dict({k: (torch.rand(v, generator=gi) * 2 - 1) / float(max(1, (v[1] * v[2] * v[3]) if len(v) == 4 else 64)) ** 0.5
+                         for k, v in shp_.items()})
+    args.logger.warning("%s not set: %s runs with RANDOMLY INITIALISED frozen weights (the trained ones are not in the "
+                        "reference repository: src/trainer.py:97 is an author-local path, vgg19(pretrained=True) a download)"
+                        % (env, type(net).__name__))
+
+
 class _ImageModel:
     """Adapter giving vlg.image_engine.ImageEngine the few methods Trainer uses on the layout engine."""
 
@@ -135,6 +159,7 @@ class _ImageModel:
         from vlg.image_engine import IMAGE_KEYS, ImageEngine
         size = _knob(args, "img_size", "VLG_IMG_SIZE", 256)
         self.size = size
+        self.args = args
         self.device = torch.device("cuda", int(args.rank))
         arch = args.arch if args.arch in ("GridNet", "CoordGridNet") else "CoordGridNet"
         from vlg.cityscapes import is_dataset_root
@@ -148,18 +173,8 @@ class _ImageModel:
         self.engine = ImageEngine(batch, size, size, self.device, arch=arch, lr=float(getattr(args, "lr", ADAM_LR)),
                                   beta1=float(getattr(args, "beta1", ADAM_BETA1)), with_hed=with_hed, with_vgg=with_vgg)
         for net, env in ((self.engine.hed, "VLG_HED_CKPT"), (self.engine.vgg, "VLG_VGG_CKPT")):
-            if net is None:
-                continue
-            path = os.environ.get(env)
-            if path:                                   # a state_dict in the reference's / torchvision's key format
-                sd_ = torch.load(path, map_location="cpu", weights_only=True)
-                net.load_state_dict(sd_.get("state_dict", sd_) if isinstance(sd_, dict) else sd_)
-            else:                                      # torch's default conv initialisation, same seed on every rank
-                gi = torch.Generator().manual_seed(int(getattr(args, "seed", SEED)) + 17)
-                shp_ = net.reference_shapes()
-                net.load_state_dict({k: (torch.rand(v, generator=gi) * 2 - 1) / float(max(1, (v[1] * v[2] * v[3]) if len(v) == 4 else 64)) ** 0.5
-                                     for k, v in shp_.items()})
-                args.logger.info("%s not set: %s runs with randomly initialised frozen weights" % (env, type(net).__name__))
+            if net is not None:
+                _load_frozen(net, env, args)
         # torch's default initialisers for Conv2d (U(+-1/sqrt(fan_in)) for weight and bias) and PReLU (0.25), from one
         # generator seeded like every rank's (main.py:57-60) so replicas start identical without a broadcast
         g = torch.Generator().manual_seed(int(getattr(args, "seed", SEED)))
@@ -172,8 +187,18 @@ class _ImageModel:
                 fan_in = (shp[1] if len(shp) == 4 else shapes[k[:-len("bias")] + "weight"][1]) * 9
                 sd[k] = (torch.rand(shp, generator=g) * 2 - 1) / fan_in ** 0.5
         self.engine.load_state_dict(sd)
+        ckpt_path = getattr(args, "ckpt", None)                       # get_gridnet's --ckpt, reference src/trainer.py:85-92
+        if ckpt_path is not None:
+            args.logger.info("Loading from ckpt %s" % ckpt_path)
+            ckpt = torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=True)
+            if "gridnet" in ckpt:
+                self.load_params(ckpt["gridnet"])                     # (the reference wrote `generator.` here: Appendix A-1)
+            if "optimizer" in ckpt:
+                self.load_optimizer(ckpt["optimizer"])
         self.world = max(int(getattr(args, "gpus", 1) or 1), 1)
         self.step_count = 0
+        self._rollouts = {}
+        self._hed_master = None
 
     def named_params(self):
         return self.engine.state_dict()
@@ -182,26 +207,37 @@ class _ImageModel:
         self.engine.load_state_dict(sd)
 
     def optimizer_state(self):
-        e = self.engine
-        return {"exp_avg": e.exp_avg.cpu().clone(), "exp_avg_sq": e.exp_avg_sq.cpu().clone(), "step": int(e.step_count),
-                "lr": e.lr, "beta1": e.beta1}
+        return self.engine.optimizer_state()
 
     def load_optimizer(self, st):
-        e = self.engine
-        e.exp_avg.copy_(st["exp_avg"]); e.exp_avg_sq.copy_(st["exp_avg_sq"]); e.step_count = int(st["step"])
+        self.engine.load_optimizer(st)
 
-    def train_step(self, batch, flip: bool):
-        e = self.engine
-        e.forward(batch, flip)
-        e.backward()
-        if self.world > 1 and dist.is_initialized():                # DDP's gradient mean (reference trainer.py:113)
-            dist.all_reduce(e.net.grads)
-        e.adam_step(1.0 / self.world)
-        return e.total().reshape(1)
+    def train_step(self, batch, flip: bool, reducer=None):
+        return self.engine.train_step(batch, flip, reducer).reshape(1)
 
     def eval_loss(self, batch):
         self.engine.forward(batch, flip=False, want_grads=False)
         return self.engine.total().reshape(1)
+
+    def _edge_net(self):
+        """The frozen HED net whose weights the rollout's twin reads: the training step's own, or (synthetic-frame
+        training feeds edge maps as inputs) one built for the purpose."""
+        if self.engine.hed is not None:
+            return self.engine.hed
+        if self._hed_master is None:
+            from vlg.hned import HNEDHIP
+            self._hed_master = HNEDHIP(1, 16, 16, self.device)        # weights only; twins are sized per call
+            _load_frozen(self._hed_master, "VLG_HED_CKPT", self.args)
+        return self._hed_master
+
+    def rollout(self, img1, img2, seg1, seg2, steps: int = 8):
+        """reference src/trainer.py:453-476 on the HIP nets (vlg.image_engine.FrameRollout)."""
+        from vlg.image_engine import FrameRollout
+        b, _, H, W = img1.shape
+        key = (int(b), int(H), int(W))
+        if key not in self._rollouts:
+            self._rollouts[key] = FrameRollout(self.engine, self._edge_net(), *key)
+        return self._rollouts[key].run(img1, img2, seg1, seg2, steps)
 
 
 class _ModelHandle:
@@ -240,6 +276,9 @@ class Trainer:
         self.reducer = None
         if self.image_mode:
             self.engine = _ImageModel(args, self.cfg.B)
+            if self.distributed:                                # replaces DDP(gridnet), trainer.py:113: bucket per grid column
+                net = self.engine.engine.net
+                self.reducer = GradReducer(net.grads_ext, net.bucket_ranges())
         else:
             self.engine = get_layout_engine(args, self.cfg, engine_factory)
             if self.distributed:                                # replaces the DDP wrappers, trainer.py:113,115
@@ -316,13 +355,13 @@ class Trainer:
             self.global_step += 1
             # forward, 40/20/10 loss, backward, bucketed all-reduce, Adam: reference src/trainer.py:209-258
             if self.image_mode:
-                loss = self.engine.train_step(batch, flip)
-                self.sync([loss])                                 # logged value = cross-rank mean (trainer.py:256)
+                loss = self.engine.train_step(batch, flip, self.reducer)
             else:
                 loss = self.engine.train_step(batch, self.reducer)
             if int(self.args.rank) == 0 and i % int(self.args.print_freq) == 0:
-                # with a reducer the 4 loss floats were summed over ranks inside the first gradient
-                # bucket: logged value = cross-rank mean, as sync() gave the reference (trainer.py:256)
+                # with a reducer the loss floats were summed over ranks inside a gradient bucket (the first one of
+                # the token step, the last one of the pixel step): logged value = cross-rank mean, as sync() gave the
+                # reference (trainer.py:256), without a collective of its own
                 value = float(loss[0].item()) / (self.world if self.reducer is not None else 1)
                 comp_time = time() - end
                 self.args.logger.info(
@@ -402,10 +441,31 @@ class Trainer:
         self.args.logger.info("Checkpoint loaded")
 
     # ----------------------------------------------------------------------- rollout
-    def generate_sequence(self, slot_class: torch.Tensor, slot_box: torch.Tensor, steps: int = 8):
-        """Autoregressive rollout, `steps` frames (8 in reference src/trainer.py:460-469): predict the frame
-        after the clip, append it, slide the T-frame window.  Inputs (B,T,N)/(B,T,N,4); returns the predicted
-        classes (B,steps,N) and boxes (B,steps,N,4) on the CPU."""
+    def generate_sequence(self, *inputs, steps: int = 8):
+        """Autoregressive rollout, `steps` predictions (8 in reference src/trainer.py:460).
+
+        VLG_MODEL=gridnet - the reference's own method: generate_sequence(img1, img2, seg1, seg2) with two
+        ImageNet-normalised frames (b,3,H,W) and two segmentation-id maps (b,1,H,W) (what eval_generate_sequence passes,
+        trainer.py:440-451).  Runs trainer.py:453-476 on the HIP nets (Appendix A-10 repaired: vlg/image_engine.py
+        FrameRollout), writes ../predict/val_<time>_{img,seg}.npy like trainer.py:474-476 and ALSO returns the two
+        arrays (b, 3*(steps+2), H, W), (b, steps+2, H, W).
+
+        Layout mode: generate_sequence(slot_class (B,T,N), slot_box (B,T,N,4)): predict the frame after the clip,
+        append it, slide the T-frame window; returns classes (B,steps,N) and boxes (B,steps,N,4) on the CPU."""
+        if self.image_mode:
+            if len(inputs) != 4:
+                raise TypeError("generate_sequence(img1, img2, seg1, seg2) in VLG_MODEL=gridnet mode")
+            import numpy as np
+            p, q = self.engine.rollout(*inputs, steps=steps)
+            p, q = p.cpu().numpy(), q.cpu().numpy()
+            t = time()
+            os.makedirs("../predict", exist_ok=True)
+            np.save("../predict/val_" + str(t) + "_img.npy", p)                   # trainer.py:474-476
+            np.save("../predict/val_" + str(t) + "_seg.npy", q)
+            return p, q
+        if len(inputs) != 2:
+            raise TypeError("generate_sequence(slot_class, slot_box) in layout mode")
+        slot_class, slot_box = inputs
         cls = slot_class.clone().to(self.device)
         box = slot_box.clone().to(self.device)
         B, T, N = cls.shape
@@ -424,8 +484,30 @@ class Trainer:
         return torch.stack(out_c, dim=1), torch.stack(out_b, dim=1)
 
     def eval_generate_sequence(self, img1, img2, seg1, seg2):
-        """main.py:64-67 entry.  The reference reads two image/seg files with cv2 (trainer.py:429-451); a
-        layout-token model has no pixel inputs, so like the reference's unreadable-path branch
-        (trainer.py:436-438) this logs and returns."""
-        self.args.logger.debug("path name not exists")
-        return None
+        """main.py:64-67 entry (reference src/trainer.py:429-451): read two frames and two segmentation-id maps from
+        files, resize the maps to 256 x 256 nearest-neighbour (:439-440; cv2.INTER_NEAREST index rule, vlg/cityscapes.py),
+        ToTensor + ImageNet-normalise the frames (:443-447), then generate_sequence.  PIL decodes the files (cv2 is not
+        installed here).  An unreadable path logs and returns like :436-438.  A layout-token model has no pixel
+        inputs: there the method raises instead of pretending a path was missing."""
+        if not self.image_mode:
+            raise NotImplementedError("eval_generate_sequence reads image files: run with VLG_MODEL=gridnet "
+                                      "(layout mode rolls out with generate_sequence(slot_class, slot_box))")
+        from vlg.cityscapes import _load_rgb, _load_seg
+        from vlg.spec import IMG_MEAN, IMG_STD
+        for pth in (img1, img2, seg1, seg2):
+            if not (isinstance(pth, str) and os.path.isfile(pth)):
+                self.args.logger.debug("path name not exists")                    # trainer.py:436-438
+                return None
+        size = self.engine.size
+        frames = [_load_rgb(pth) for pth in (img1, img2)]
+        segs = [_load_seg(pth, (size, size)).float()[None, None] for pth in (seg1, seg2)]
+        for f in frames:
+            if tuple(f.shape[1:]) != (size, size):
+                raise ValueError("frames must be %d x %d like the reference's pre-scaled leftImg256 (got %s)"
+                                 % (size, size, tuple(f.shape[1:])))
+        mean = torch.tensor(IMG_MEAN)[:, None, None]
+        std = torch.tensor(IMG_STD)[:, None, None]
+        frames = [((f - mean) / std)[None] for f in frames]                       # transforms.Normalize, :443-447
+        self.args.logger.debug(segs[0].shape)
+        self.args.logger.debug(frames[0].shape)
+        return self.generate_sequence(frames[0], frames[1], segs[0], segs[1])

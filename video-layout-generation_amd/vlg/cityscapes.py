@@ -79,13 +79,24 @@ def _load_rgb(path: str) -> torch.Tensor:
     return torch.from_numpy(a.copy()).permute(2, 0, 1).float().div_(255.0)         # ToTensor: HWC uint8 -> CHW [0,1]
 
 
+def resize_nearest_cv2(a: np.ndarray, size: Tuple[int, int]) -> np.ndarray:
+    """cv2.resize(a, dsize, interpolation=cv2.INTER_NEAREST) (reference src/folder.py:133, src/trainer.py:439-440) by its
+    published index rule - destination pixel (y, x) takes source (min(floor(y * H/h), H-1), min(floor(x * W/w), W-1)) -
+    which is NOT PIL's NEAREST (that samples at pixel centres, floor((x + 0.5) * W/w)).  cv2 is absent here, so this
+    restatement is unpinned against cv2 itself; an 8x downscale picks rows 0, 8, 16 ... as OpenCV's resizeNN does."""
+    H, W = a.shape[:2]
+    h, w = size
+    ys = np.minimum(np.floor(np.arange(h) * (H / h)).astype(np.int64), H - 1)
+    xs = np.minimum(np.floor(np.arange(w) * (W / w)).astype(np.int64), W - 1)
+    return a[ys][:, xs]
+
+
 def _load_seg(path: str, size: Tuple[int, int]) -> torch.Tensor:
     from PIL import Image
     with Image.open(path) as im:
-        im = im.convert("L")
-        if im.size != (size[1], size[0]):
-            im = im.resize((size[1], size[0]), Image.NEAREST)                      # folder.py:133 (INTER_NEAREST)
-        a = np.asarray(im, dtype=np.uint8)
+        a = np.asarray(im.convert("L"), dtype=np.uint8)
+    if a.shape != tuple(size):
+        a = resize_nearest_cv2(a, size)                                            # folder.py:133 (INTER_NEAREST)
     return torch.from_numpy(a.copy())
 
 

@@ -30,6 +30,30 @@ def _ceil32(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
+def reference_param_order(coord: bool) -> List[str]:
+    """Keys in the order the reference constructors register their parameters (reference src/models/gridnet.py:19-39 /
+    :75-95, src/models/modules.py:10-25,34-39,49-55,118-135) = module.parameters() order = the index space of the
+    torch.optim.Adam state_dict the reference's get_gridnet builds and loads (src/trainer.py:83,91-92)."""
+    def blk(name: str, kind: str = "lateral") -> List[str]:
+        seq, i = ("up", (1, 2, 3, 4)) if kind == "up" else ("conv", (0, 1, 2, 3))
+        return ["%s.%s.%d.weight" % (name, seq, i[0]), "%s.%s.%d.weight" % (name, seq, i[1]), "%s.%s.%d.bias" % (name, seq, i[1]),
+                "%s.%s.%d.weight" % (name, seq, i[2]), "%s.%s.%d.weight" % (name, seq, i[3]), "%s.%s.%d.bias" % (name, seq, i[3])]
+    if coord:
+        out = ["lateral_in.conv.0.conv.weight", "lateral_in.conv.0.conv.bias", "lateral_in.conv.1.weight",
+               "lateral_in.conv.2.conv.weight", "lateral_in.conv.2.conv.bias", "lateral_in.conv2.conv.weight",
+               "lateral_in.conv2.conv.bias"]
+    else:
+        out = blk("lateral_in") + ["lateral_in.conv2.weight", "lateral_in.conv2.bias"]
+    out += blk("lateral_out_seg") + blk("lateral_out_img") + blk("down_00") + blk("down_10")
+    for i in (1, 2):
+        out += blk("lateral_0%d" % (i - 1)) + blk("down_0%d" % i) + blk("down_1%d" % i) + blk("lateral_1%d" % (i - 1)) + \
+            blk("lateral_2%d" % (i - 1))
+    for i in (3, 4, 5):
+        out += blk("lateral_2%d" % (i - 1)) + blk("lateral_1%d" % (i - 1)) + blk("lateral_0%d" % (i - 1)) + \
+            blk("up_1%d" % i, "up") + blk("up_0%d" % i, "up")
+    return out
+
+
 class _Geo:
     """One resolution level: padded geometry, interior mask, stride-2 tables to the next coarser level."""
 
@@ -90,8 +114,13 @@ class _Conv:
 
 
 class GridNetHIP:
+    TAIL_EXTRA = 8
+
     def __init__(self, n_channels: int, batch: int, H: int, W: int, device, coord: bool = False,
-                 filters=(32, 64, 96), seg_out: int = 20, img_out: int = 3, need_input_grad: bool = False):
+                 filters=(32, 64, 96), seg_out: int = 20, img_out: int = 3, need_input_grad: bool = False,
+                 params_from: Optional["GridNetHIP"] = None):
+        """params_from: build a FORWARD-ONLY twin of another instance (other batch / image size) that reads that
+        instance's parameter buffer - the rollout and validation-time shapes share the training weights, no copy."""
         if H % 4 or W % 4:
             raise ValueError("H and W must be divisible by 4 (two stride-2 levels)")
         hip.load()
@@ -108,6 +137,9 @@ class GridNetHIP:
         self.prelu_keys: List[str] = []
         f = self.filters
         # ---- build the static graph in the reference's forward order (gridnet.py:43-58 / :99-114)
+        # `_group` tags every convolution with the gradient bucket it belongs to: backward finishes the heads first, then
+        # grid columns 5 .. 1, then the input blocks - the order data-parallel buckets are handed to the reducer
+        self._group = "in"
         self.x = self._tensor(0, n_channels, coord=coord)
         if coord:      # CoordLateralBlock: [CoordConv, PReLU, CoordConv] + CoordConv shortcut (modules.py:115-135)
             t = self._conv("lateral_in.conv.0.conv", self.x, f[0], out_coord=True)
@@ -119,6 +151,7 @@ class GridNetHIP:
         x1 = self._block("down_00", "down", x0, f[1])
         x2 = self._block("down_10", "down", x1, f[2])
         for i in range(1, 6):
+            self._group = "col%d" % i
             if i < 3:
                 x0 = self._block("lateral_0%d" % (i - 1), "lateral", x0, f[0])
                 d = self._block("down_0%d" % i, "down", x0, f[1])
@@ -131,9 +164,13 @@ class GridNetHIP:
                 x1 = self._block("lateral_1%d" % (i - 1), "lateral", x1, f[1], resid=u)
                 u = self._block("up_0%d" % i, "up", x1, f[0])
                 x0 = self._block("lateral_0%d" % (i - 1), "lateral", x0, f[0], resid=u)
+        self._group = "head"
         self.seg = self._block("lateral_out_seg", "lateral", x0, seg_out)
         self.img = self._block("lateral_out_img", "lateral", x0, img_out)
-        self._alloc_params()
+        self._alloc_params(params_from)
+        self.forward_only = params_from is not None
+        if self.forward_only:
+            return
         lib = hip.load()
         # Backward scratch: every convolution owns a region of the slab arena (weight-gradient partials) and, if a PReLU
         # precedes it, of the slope-gradient arena; two table-driven launches at the end of backward() reduce them all
@@ -158,6 +195,17 @@ class GridNetHIP:
         self.da_table = torch.tensor(drows, dtype=torch.int64).to(device) if drows else None
         self.n_da = len(drows)
         self.n_convs = len(convs)
+        # gradient buckets: (tag, first conv, one past the last conv, first float, one past the last float), convs of a
+        # group are consecutive on the tape and so are their parameters
+        self.groups: List[Tuple[str, int, int, int, int]] = []
+        for i, c in enumerate(convs):
+            c.index = i
+            if self.groups and self.groups[-1][0] == c.group:
+                tag, lo, _, start, _ = self.groups[-1]
+                self.groups[-1] = (tag, lo, i + 1, start, c.b_off + c.out.cp)
+            else:
+                self.groups.append((c.group, i, i + 1, c.w_off, c.b_off + c.out.cp))
+        self._group_of_first = {lo: g for g in self.groups for lo in (g[1],)}
 
     # ------------------------------------------------------------------ graph construction
     def _tensor(self, level: int, C: int, coord: bool = False) -> _PT:
@@ -173,6 +221,7 @@ class GridNetHIP:
         out = self._tensor(x.level + (1 if stride == 2 else 0), cout, coord=out_coord)
         cin = x.C + (2 if x.coord_c0 >= 0 else 0)
         op = _Conv(key, x, out, cin, cout, stride, prelu, resid, act_ch if act_ch is not None else x.cp)
+        op.group = self._group
         if prelu is not None:
             self.prelu_keys.append(prelu)
         self.tape.append(op)
@@ -187,7 +236,7 @@ class GridNetHIP:
         t = self._conv(name + ".conv.1", x, cout, stride=2 if kind == "down" else 1, prelu=name + ".conv.0.weight")
         return self._conv(name + ".conv.3", t, cout, prelu=name + ".conv.2.weight", resid=resid)
 
-    def _alloc_params(self) -> None:
+    def _alloc_params(self, params_from: Optional["GridNetHIP"] = None) -> None:
         off = 0
         self.p_off: Dict[str, int] = {}
         for op in self.tape:
@@ -200,8 +249,17 @@ class GridNetHIP:
             self.p_off[k] = off
             off += 4
         self.n_params_padded = off
+        if params_from is not None:
+            if (params_from.coord, params_from.filters, params_from.n_channels, params_from.n_params_padded) != \
+                    (self.coord, self.filters, self.n_channels, off):
+                raise ValueError("params_from must be the same architecture")
+            self.params, self.grads = params_from.params, None
+            return
         self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(off, dtype=torch.float32, device=self.device)
+        # TAIL_EXTRA floats after the last parameter carry the step's loss scalars, so they travel inside the last
+        # data-parallel gradient bucket instead of a collective of their own (reference src/trainer.py:256 spent one)
+        self.grads_ext = torch.zeros(off + self.TAIL_EXTRA, dtype=torch.float32, device=self.device)
+        self.grads = self.grads_ext[:off]
 
     # --------------------------------------------------------------------------- parameters
     def reference_shapes(self) -> "OrderedDict[str, Tuple[int, ...]]":
@@ -216,24 +274,36 @@ class GridNetHIP:
             s[k] = (1,)
         return s
 
-    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
-        """Reference-format tensors ([cout,cin,3,3] weights, [1] slopes) -> kernel layout."""
+    def pack(self, sd: Dict[str, torch.Tensor], flat: torch.Tensor) -> None:
+        """Reference-format tensors ([cout,cin,3,3] weights, [cout] biases, [1] slopes) -> a flat buffer in the kernel
+        layout (padded lanes zero).  Used for the parameters and for per-parameter optimiser state alike."""
         want = self.reference_shapes()
         missing = [k for k in want if k not in sd]
         if missing:
             raise KeyError("state_dict lacks %s" % missing[:4])
-        self.params.zero_()
+        if flat.numel() != self.n_params_padded:
+            raise ValueError("flat buffer has %d floats, layout needs %d" % (flat.numel(), self.n_params_padded))
+        for k, shp in want.items():
+            if tuple(sd[k].shape) != tuple(shp):
+                raise ValueError("%s has shape %s, expected %s" % (k, tuple(sd[k].shape), tuple(shp)))
+        flat.zero_()
         for op in self.tape:
             if isinstance(op, _Conv):
                 w = sd[op.key + ".weight"].to(torch.float32)
-                if tuple(w.shape) != (op.cout, op.cin, 3, 3):
-                    raise ValueError("%s.weight has shape %s, expected %s" % (op.key, tuple(w.shape), (op.cout, op.cin, 3, 3)))
                 wp = torch.zeros(op.out.cp, 9, op.x.cp)
                 wp[:op.cout, :, :op.cin] = w.permute(0, 2, 3, 1).reshape(op.cout, 9, op.cin)
-                self.params[op.w_off:op.w_off + wp.numel()].copy_(wp.flatten())
-                self.params[op.b_off:op.b_off + op.cout].copy_(sd[op.key + ".bias"].to(torch.float32))
+                flat[op.w_off:op.w_off + wp.numel()].copy_(wp.flatten())
+                flat[op.b_off:op.b_off + op.cout].copy_(sd[op.key + ".bias"].to(torch.float32))
         for k in self.prelu_keys:
-            self.params[self.p_off[k]:self.p_off[k] + 1].copy_(sd[k].to(torch.float32).flatten())
+            flat[self.p_off[k]:self.p_off[k] + 1].copy_(sd[k].to(torch.float32).flatten())
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Reference-format state_dict (reference src/trainer.py:89-90 'gridnet') -> the parameter buffer."""
+        self.pack(sd, self.params)
+
+    def unpack(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Inverse of pack(): flat kernel-layout buffer -> {reference key: tensor} on the CPU."""
+        return self._export(flat)
 
     def _export(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         out = {}
@@ -252,6 +322,19 @@ class GridNetHIP:
 
     def named_grads(self) -> Dict[str, torch.Tensor]:
         return self._export(self.grads)
+
+    def prelu_inputs(self) -> Dict[str, torch.Tensor]:
+        """{PReLU key: its input of the last forward, (b,C,H,W)} - diagnostics / tests: which side of the kink
+        every pre-activation fell on (the activation is applied by the consuming conv on load, so the stored
+        tensor IS the pre-activation)."""
+        out, s = {}, self._stream()
+        for op in self.tape:
+            if isinstance(op, _Conv) and op.prelu:
+                g, C = op.x.geo, op.x.C
+                t = torch.empty(g.b, C, g.H, g.W, dtype=torch.float32, device=self.device)
+                call("vlg_padded_to_nchw", op.x.ptr, ptr(t), g.b, C, g.H, g.W, op.x.cp, s)
+                out[op.prelu] = t
+        return out
 
     # ------------------------------------------------------------------------------ forward
     @staticmethod
@@ -292,9 +375,21 @@ class GridNetHIP:
             assert t.grad.cp == t.cp
         return t.grad
 
-    def backward(self, dseg: torch.Tensor, dimg: torch.Tensor) -> Optional[torch.Tensor]:
+    def bucket_ranges(self) -> List[Tuple[str, int, int]]:
+        """[(tag, start, end)] over grads_ext in the order backward completes them (vlg.dp.GradReducer): heads, grid
+        columns 5..1, the input blocks, and a tail bucket = every PReLU slope + the TAIL_EXTRA loss floats."""
+        out = [(tag, start, end) for tag, _, _, start, end in reversed(self.groups)]
+        out.append(("tail", self.groups[-1][4], self.n_params_padded + self.TAIL_EXTRA))
+        return out
+
+    def backward(self, dseg: torch.Tensor, dimg: torch.Tensor, reducer=None) -> Optional[torch.Tensor]:
         """Parameter gradients of sum(seg*dseg) + sum(img*dimg) into self.grads (overwritten).  Returns the
-        input gradient (NCHW) when built with need_input_grad."""
+        input gradient (NCHW) when built with need_input_grad.  With a `reducer` (vlg.dp.GradReducer over grads_ext,
+        buckets = bucket_ranges()) each bucket's partial sums are reduced as soon as its last convolution is done and
+        the bucket is handed over, so its all-reduce overlaps the rest of backward (DDP's overlap, reference
+        src/trainer.py:113); without one, a single table-driven launch reduces everything at the end."""
+        if self.forward_only:
+            raise RuntimeError("this GridNetHIP was built forward-only (params_from)")
         lib = hip.load()
         s = self._stream()
         g0 = self.geo[0]
@@ -330,16 +425,23 @@ class GridNetHIP:
                     gr = self._grad_of(op.resid)
                     call("vlg_add_rows", gr.ptr, dout.ptr, dout.n, 1 if op.resid.grad_written else 0, s)
                     op.resid.grad_written = True
+                if reducer is not None and op.index in self._group_of_first:       # bucket complete
+                    tag, lo, hi, _, _ = self._group_of_first[op.index]
+                    call("vlg_reduce_slabs_table", self.reduce_table.data_ptr() + 40 * lo, hi - lo, 64, s)
+                    reducer.ready(tag)
             else:
                 _, src, dst = op
                 gs = self._grad_of(src)
                 call("vlg_upsample2x_bwd", dst.grad.ptr, gs.ptr, src.geo.b, src.geo.H, src.geo.W, src.cp,
                      1 if src.grad_written else 0, s)
                 src.grad_written = True
-        # every weight / bias gradient and every PReLU slope gradient, two launches
-        call("vlg_reduce_slabs_table", ptr(self.reduce_table), self.n_convs, 64, s)
+        # every weight / bias gradient (unless reduced bucket by bucket above) and every PReLU slope gradient
+        if reducer is None:
+            call("vlg_reduce_slabs_table", ptr(self.reduce_table), self.n_convs, 64, s)
         if self.da_table is not None:
             call("vlg_sum_partials_table", ptr(self.da_table), self.n_da, s)
+        if reducer is not None:
+            reducer.ready("tail")
         if self.need_input_grad:
             dx = torch.empty(g0.b, self.n_channels, g0.H, g0.W, dtype=torch.float32, device=self.device)
             call("vlg_padded_to_nchw", self.x.grad.ptr, ptr(dx), g0.b, self.n_channels, g0.H, g0.W, self.x.cp, s)

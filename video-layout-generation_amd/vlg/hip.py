@@ -55,6 +55,8 @@ SIGNATURES = {
     "vlg_ssim_loss": (I, [P, P, P, P, P, I, I, I, I, F, P]),
     "vlg_affine_nchw": (I, [P, P, I, I, L, P, P, P]),
     "vlg_prep_input": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "vlg_argmax_nchw": (I, [P, P, I, I, L, P]),
+    "vlg_rollout_input": (I, [P, P, P, P, P, P, P, I, L, P]),
     "vlg_conv3x3_fwd": (I, [P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, P, L, P]),
     "vlg_conv3x3_fwd_splits": (I, [L, I, I, I]),
     "vlg_conv3x3_dgrad_slabs": (I, [L, I]),

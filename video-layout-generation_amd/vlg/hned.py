@@ -29,7 +29,8 @@ BGR_MEAN = (104.00698793, 116.66876762, 122.67891434)      # hned.py:74-76 (appl
 
 
 class HNEDHIP:
-    def __init__(self, batch: int, H: int, W: int, device):
+    def __init__(self, batch: int, H: int, W: int, device, params_from: "HNEDHIP" = None):
+        """params_from: twin for another batch / image size reading that instance's weights (no copy)."""
         if H % 16 or W % 16:
             raise ValueError("H and W must be divisible by 16 (four 2x2 max-pools)")
         hip.load()
@@ -72,7 +73,7 @@ class HNEDHIP:
         off += 4
         self.off["_zero"] = off                       # ReLU = PReLU with slope 0
         off += 4
-        self.params = torch.zeros(off, dtype=torch.float32, device=device)
+        self.params = torch.zeros(off, dtype=torch.float32, device=device) if params_from is None else params_from.params
         self.score = [torch.empty(batch, H >> k, W >> k, dtype=torch.float32, device=device) for k in range(5)]
         # split-K workspace of the coarse levels (vlg_conv3x3_fwd_splits partial tiles; None when no conv splits)
         lib = hip.load()

@@ -26,9 +26,9 @@ from typing import Dict, Optional
 import torch
 
 from . import hip
-from .gridnet import GridNetHIP
+from .gridnet import GridNetHIP, reference_param_order
 from .hip import call, ptr
-from .spec import ADAM_BETA1, ADAM_BETA2, ADAM_EPS, ADAM_LR, OUT_MEAN, OUT_STD
+from .spec import ADAM_BETA1, ADAM_BETA2, ADAM_EPS, ADAM_LR, IMG_MEAN, IMG_STD, OUT_MEAN, OUT_STD
 
 IMAGE_KEYS = ("frame1", "seg1", "frame2", "seg2", "frame3", "seg3", "e1", "e2")
 W_L1, W_STYLE, W_CE = 40.0, 20.0, 10.0          # reference src/trainer.py:248-250
@@ -63,7 +63,9 @@ class ImageEngine:
         self.dtmp = torch.empty(batch, 3, H, W, **f32)
         self.dseg = torch.empty(batch, 20, H, W, **f32)
         self.scratch = torch.zeros(hip.load().vlg_image_loss_scratch(), **f32)
-        self.losses = torch.zeros(8, **f32)          # {l1, gradient, ssim, ce, vgg, -, -, -}
+        # {l1, gradient, ssim, ce, vgg, -, -, -}: the 8 floats behind the last gradient, so under data parallelism
+        # they ride in the last gradient bucket (vlg/gridnet.py TAIL_EXTRA)
+        self.losses = self.net.grads_ext[self.net.n_params_padded:]
         arr = ctypes.c_float * 3
         self._mean, self._istd = arr(*OUT_MEAN), arr(*[1.0 / s for s in OUT_STD])
         self._zero = arr(0.0, 0.0, 0.0)
@@ -77,6 +79,53 @@ class ImageEngine:
 
     def state_dict(self):
         return self.net.state_dict()
+
+    # ------------------------------------------------------------------ optimiser state (checkpoints)
+    def optimizer_state(self) -> Dict[str, object]:
+        """Adam state in torch.optim.Adam.state_dict() form - {'state': {i: {'step','exp_avg','exp_avg_sq'}},
+        'param_groups': [...]} with i indexing the reference model's parameters() order and tensors in the reference's
+        shapes - i.e. what reference src/trainer.py:91-92 loads into its own optimizer ('optimizer' entry of --ckpt)."""
+        order = reference_param_order(self.net.coord)
+        state = {}
+        if self.step_count > 0:                      # torch keeps no per-parameter state before the first step
+            m, v = self.net.unpack(self.exp_avg), self.net.unpack(self.exp_avg_sq)
+            state = {i: {"step": torch.tensor(float(self.step_count)), "exp_avg": m[k], "exp_avg_sq": v[k]}
+                     for i, k in enumerate(order)}
+        group = {"lr": self.lr, "betas": (self.beta1, ADAM_BETA2), "eps": ADAM_EPS, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer(self, st: Dict[str, object]) -> None:
+        """Accepts a torch.optim.Adam state_dict over the reference model's parameters (reference trainer.py:92) - mapped
+        parameter by parameter into the kernels' flat layout - or the flat {'exp_avg','exp_avg_sq','step'} form."""
+        n = self.net.params.numel()
+        if "state" in st and "param_groups" in st:
+            order = reference_param_order(self.net.coord)
+            ids = [i for g in st["param_groups"] for i in g["params"]]
+            if len(ids) != len(order):
+                raise ValueError("optimizer state covers %d parameters, %s has %d"
+                                 % (len(ids), "CoordGridNet" if self.net.coord else "GridNet", len(order)))
+            state = st["state"]
+            if len(state) == 0:
+                self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count = 0
+                return
+            missing = [i for i in ids if i not in state]
+            if missing:
+                raise ValueError("optimizer state lacks entries for parameter ids %s" % missing[:4])
+            steps = {int(float(state[i]["step"])) for i in ids}
+            if len(steps) != 1:
+                raise ValueError("per-parameter step counts differ (%s): one flat Adam step cannot represent that" % sorted(steps)[:4])
+            self.net.pack({k: state[i]["exp_avg"] for i, k in zip(ids, order)}, self.exp_avg)
+            self.net.pack({k: state[i]["exp_avg_sq"] for i, k in zip(ids, order)}, self.exp_avg_sq)
+            self.step_count = steps.pop()
+            return
+        for k in ("exp_avg", "exp_avg_sq", "step"):
+            if k not in st:
+                raise ValueError("optimizer state is neither a torch.optim.Adam state_dict nor the flat form (no %r)" % k)
+        if st["exp_avg"].numel() != n or st["exp_avg_sq"].numel() != n:
+            raise ValueError("optimizer state has %d elements, model has %d" % (st["exp_avg"].numel(), n))
+        self.exp_avg.copy_(st["exp_avg"]); self.exp_avg_sq.copy_(st["exp_avg_sq"]); self.step_count = int(st["step"])
 
     def forward(self, batch: Dict[str, torch.Tensor], flip: bool = False, want_grads: bool = True) -> torch.Tensor:
         """Forward + losses (+ d loss / d outputs).  Returns the device scalar-array {l1, gd, ssim, ce}."""
@@ -117,21 +166,89 @@ class ImageEngine:
         L = self.losses
         return W_L1 * L[0] + W_STYLE * (L[1] + L[2] + L[4]) + W_CE * L[3]
 
-    def backward(self) -> None:
+    def backward(self, reducer=None) -> None:
         b, H, W, s = self.b, self.H, self.W, self._stream()
         call("vlg_affine_nchw", ptr(self.dimg), ptr(self.dtmp), b, 3, H * W, self._zero, self._istd, s)   # d/d img_raw
-        self.net.backward(self.dseg, self.dtmp)
+        self.net.backward(self.dseg, self.dtmp, reducer)
 
     def adam_step(self, grad_scale: float = 1.0) -> None:
         self.step_count += 1
         call("vlg_adam_step", ptr(self.net.params), ptr(self.net.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
              self.net.params.numel(), self.step_count, self.lr, self.beta1, ADAM_BETA2, ADAM_EPS, grad_scale, self._stream())
 
-    def train_step(self, batch, flip: bool = False) -> torch.Tensor:
+    def train_step(self, batch, flip: bool = False, reducer=None) -> torch.Tensor:
+        """forward -> losses -> backward (+ bucketed gradient all-reduce overlapped with it) -> Adam.  Returns the total
+        loss (summed over ranks when a reducer is attached: the loss floats travel in the last bucket)."""
         self.forward(batch, flip)
-        self.backward()
-        self.adam_step()
+        self.backward(reducer)
+        if reducer is not None:
+            reducer.wait()
+            self.adam_step(reducer.grad_scale)                     # 1/world: DDP's gradient mean, trainer.py:113
+        else:
+            self.adam_step()
         return self.total()
+
+
+class FrameRollout:
+    """Autoregressive prediction of the next frames, reference src/trainer.py:453-476 (generate_sequence), forward only.
+
+    Starting from two ImageNet-normalised frames and their segmentation-id maps (what eval_generate_sequence hands
+    over, trainer.py:440-450), `steps` (8 in the reference) times:
+        x = cat[e(-2), seg[-2], img[-2], img[-1], seg[-1], e(-1)]            trainer.py:461
+        seg_next, img_next = gridnet(x)                                      :464
+        img_next = (img_next - mean_arr) / std_arr                           :466
+        seg_next = argmax(seg_next, dim=1) as float                          :467
+    and the lists grow by the prediction (:468-469).  Returns (p, q) = cat(img, dim=1), cat(seg, dim=1) - the two
+    arrays the reference saves to ../predict (:470-476): (b, 3*(steps+2), H, W) and (b, steps+2, H, W).
+
+    Repair of SURVEY.md Appendix A-10, stated: the reference concatenates 8 channels for a network built with
+    n_channels=10 (trainer.py:82) and calls an undefined self.netG.  The two missing channels are the edge maps the
+    network was trained with (trainer.py:190-197): e = hed(frame)[5] on the frame in [0,1], i.e. on
+    img * img_std + img_mean exactly as trainer.py:214-216 feeds its own prediction back to the edge net; channel
+    order is the training input's.  The nets are forward-only twins of the training nets (shared weights) sized for
+    this batch."""
+
+    def __init__(self, engine: "ImageEngine", hed, batch: int, H: int, W: int):
+        from .hned import HNEDHIP
+        self.device, self.b, self.H, self.W = engine.device, batch, H, W
+        src = engine.net
+        self.net = GridNetHIP(10, batch, H, W, self.device, coord=src.coord, filters=src.filters, params_from=src)
+        self.hed = HNEDHIP(batch, H, W, self.device, params_from=hed)
+        arr = ctypes.c_float * 3
+        self._mean, self._istd = arr(*OUT_MEAN), arr(*[1.0 / s for s in OUT_STD])
+        # frame in [0,1] = img * img_std + img_mean  (trainer.py:215) as (img - shift) * scale
+        self._unshift, self._unscale = arr(*[-m / s for m, s in zip(IMG_MEAN, IMG_STD)]), arr(*IMG_STD)
+        self.x10 = torch.empty(batch, 10, H, W, dtype=torch.float32, device=self.device)
+        self.frame01 = torch.empty(batch, 3, H, W, dtype=torch.float32, device=self.device)
+
+    def _edges(self, img: torch.Tensor) -> torch.Tensor:
+        s = torch.cuda.current_stream().cuda_stream
+        call("vlg_affine_nchw", ptr(img), ptr(self.frame01), self.b, 3, self.H * self.W, self._unshift, self._unscale, s)
+        return self.hed.forward(self.frame01)[5].contiguous()          # fused map (hned.py:105), (b,H,W)
+
+    def run(self, img1, img2, seg1, seg2, steps: int = 8):
+        b, H, W, dev = self.b, self.H, self.W, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        want = {"img": (b, 3, H, W), "seg": (b, 1, H, W)}
+        for name, t, kind in (("img1", img1, "img"), ("img2", img2, "img"), ("seg1", seg1, "seg"), ("seg2", seg2, "seg")):
+            if tuple(t.shape) != want[kind]:
+                raise ValueError("%s must have shape %s, got %s" % (name, want[kind], tuple(t.shape)))
+        img = [img1.to(**f32).contiguous(), img2.to(**f32).contiguous()]             # trainer.py:455-458
+        seg = [seg1.to(**f32).contiguous(), seg2.to(**f32).contiguous()]
+        edge = [self._edges(img[0]), self._edges(img[1])]
+        s = torch.cuda.current_stream().cuda_stream
+        for _ in range(steps):                                                       # trainer.py:460
+            call("vlg_rollout_input", ptr(edge[-2]), ptr(seg[-2]), ptr(img[-2]), ptr(img[-1]), ptr(seg[-1]), ptr(edge[-1]),
+                 ptr(self.x10), b, H * W, s)
+            seg_logits, img_raw = self.net.forward(self.x10)
+            nxt = torch.empty(b, 3, H, W, **f32)
+            call("vlg_affine_nchw", ptr(img_raw), ptr(nxt), b, 3, H * W, self._mean, self._istd, s)
+            ids = torch.empty(b, 1, H, W, **f32)
+            call("vlg_argmax_nchw", ptr(seg_logits), ptr(ids), b, seg_logits.shape[1], H * W, s)
+            img.append(nxt)
+            seg.append(ids)
+            edge.append(self._edges(nxt))
+        return torch.cat(img, dim=1), torch.cat(seg, dim=1)                          # trainer.py:470-471
 
 
 def synthetic_frames(n: int, H: int, W: int, seed: int = 1024) -> Dict[str, torch.Tensor]:
