@@ -99,6 +99,10 @@ int vlg_layernorm_bwd_bf16(const vlg_bf16* dy, const float* x, const float* mean
 #define VLG_EPI_SPLIT3 256  /* fp32 tensors, fp32-grade result on the bf16 matrix cores: each operand is split exactly into
                               three bf16 terms and a product block is six v_mfma_f32_32x32x16_bf16 (a1b1 + a1b2 + a2b1 +
                               a1b3 + a2b2 + a3b1, fp32 accumulate; the dropped terms are <= 3 * 2^-24 |a||b|)          */
+#define VLG_EPI_ACT_GELU 512 /* native fp32 path: the activation operand (A of vlg_linear_fwd with BIAS | RESID, X of
+                              vlg_linear_wgrad) holds PRE-activations and passes through GELU on its way to LDS - the
+                              FFN hidden activation gelu(u) is then never written to HBM: the first projection stores
+                              u only (plain BIAS epilogue), the second projection and its weight gradient recompute    */
 /* bf16 ACTIVATION STORAGE (with VLG_EPI_BF16 only): the activation operands named below are vlg_bf16 arrays in
  * HBM instead of float - half the bytes of a mode that is HBM-bound.  Biases, gradient slabs, master weights and
  * the residual stream stay fp32; leading dimensions count elements.                                             */

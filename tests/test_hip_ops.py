@@ -138,6 +138,35 @@ def test_linear_fwd_gelu_and_resid(H, dev, M, N, K):
     assert_close(c, (pre + r.double()).float(), what="linear + residual")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 1024), (300, 128, 512), (1000, 256, 96)])
+def test_linear_gelu_on_load(H, dev, M, N, K):
+    """VLG_EPI_ACT_GELU: the activation operand holds PRE-activations u and gelu(u) is formed while the tile is staged -
+    forward  C = gelu(u) . W^T + b + resid  and weight gradient  dW = dY^T . gelu(u)  (the FFN's second projection)."""
+    torch.manual_seed(7)
+    u, w, b, r = torch.randn(M, K) * 1.5, torch.randn(N, K) / math.sqrt(K), torch.randn(N), torch.randn(M, N)
+    dy = torch.randn(M, N)
+    g = F.gelu(u.double())
+    ud, wd, bd, rd, dyd = u.to(dev), w.to(dev), b.to(dev), r.to(dev), dy.to(dev)
+    c = torch.full((M, N), float("nan"), device=dev)
+    H.call("vlg_linear_fwd", ud.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, rd.data_ptr(), 0,
+           M, N, K, H.EPI_BIAS | H.EPI_RESID | H.EPI_ACT_GELU, stream())
+    assert_close(c, (F.linear(g, w.double(), b.double()) + r.double()).float(), rtol=1e-4, atol=1e-5, what="gelu-on-load fwd")
+    assert torch.equal(ud.cpu(), u)                                      # the stored pre-activation is untouched
+    ns = H.load().vlg_linear_wgrad_slabs(M, N, K)
+    stride = N * K + N
+    slabs = torch.full((ns * stride,), float("nan"), device=dev)
+    H.call("vlg_linear_wgrad", dyd.data_ptr(), N, ud.data_ptr(), K, slabs.data_ptr(), stride, slabs.numel(), M, N, K,
+           H.EPI_ACT_GELU, stream())
+    gr = reduce_slabs(H, slabs, stride, ns, stride, dev)
+    sc = math.sqrt(M)
+    assert_close(gr[:N * K].view(N, K) / sc, (dy.double().t() @ g).float() / sc, rtol=1e-4, atol=1e-5, what="gelu-on-load wgrad")
+    assert_close(gr[N * K:] / sc, dy.double().sum(0).float() / sc, rtol=1e-4, atol=1e-5, what="bias grad")
+    # only the native fp32 path implements it: the other modes refuse instead of silently ignoring the flag
+    rc = H.load().vlg_linear_fwd(ud.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, rd.data_ptr(), 0,
+                                 M, N, K, H.EPI_BIAS | H.EPI_RESID | H.EPI_ACT_GELU | H.EPI_BF16, stream())
+    assert rc == 1001
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 768, 256), (200, 256, 1024), (384, 1024, 256), (500, 24, 256), (128, 64, 64)])
 def test_linear_dgrad_wgrad(H, dev, M, N, K):
     torch.manual_seed(4)

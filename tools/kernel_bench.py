@@ -14,7 +14,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "video-layout-generation_amd")]
 import torch  # noqa: E402
 
 from vlg import hip  # noqa: E402
-from vlg.hip import EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID  # noqa: E402
+from vlg.hip import EPI_ACT_GELU, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID  # noqa: E402
 
 
 def main():
@@ -59,6 +59,12 @@ def main():
     add("gemm fwd proj (bias+resid)", fl(d, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_proj), d, P(bias), P(y_d), d, P(x_d), 0, M, d, d, EPI_BIAS | EPI_RESID | FLAGS, S))
     add("gemm fwd ff1  (bias+gelu)", fl(ff, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_ff1), d, P(bias), P(y_ff), ff, 0, P(x_ff2), M, ff, d, EPI_BIAS | EPI_GELU | FLAGS, S))
     add("gemm fwd ff2  (bias+resid)", fl(d, ff), "F", lambda: hip.call("vlg_linear_fwd", P(x_ff), ff, P(w_ff2), ff, P(bias), P(y_d), d, P(x_d), 0, M, d, ff, EPI_BIAS | EPI_RESID | FLAGS, S))
+    if not a.bf16:   # native fp32 step: gelu(u) is never stored (VLG_EPI_ACT_GELU)
+        add("gemm fwd ff1  (bias, u only)", fl(ff, d), "F", lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_ff1), d, P(bias), P(y_ff), ff, 0, 0, M, ff, d, EPI_BIAS, S))
+        add("gemm fwd ff2  (gelu on load)", fl(d, ff), "F", lambda: hip.call("vlg_linear_fwd", P(x_ff), ff, P(w_ff2), ff, P(bias), P(y_d), d, P(x_d), 0, M, d, ff, EPI_BIAS | EPI_RESID | EPI_ACT_GELU, S))
+    # asymptote of the main loop: the same tile with a long contraction (prologue / epilogue amortised over 128 K tiles)
+    x_long, w_long = r(M // 4, 4096), r(ff, 4096)
+    add("gemm fwd asymptote K=4096 (M/4)", 2.0 * (M // 4) * ff * 4096, "F", lambda: hip.call("vlg_linear_fwd", P(x_long), 4096, P(w_long), 4096, P(bias), P(y_ff), ff, 0, 0, M // 4, ff, 4096, EPI_BIAS | FLAGS, S))
     add("gemm dgrad qkv", fl(3 * d, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_3d), 3 * d, P(w_qkv), d, P(y_d), d, 0, M, 3 * d, d, EPI_NONE | FLAGS, S))
     add("gemm dgrad proj", fl(d, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_proj), d, P(y_d), d, 0, M, d, d, EPI_NONE | FLAGS, S))
     add("gemm dgrad ff1", fl(ff, d), "F", lambda: hip.call("vlg_linear_dgrad", P(x_ff), ff, P(w_ff1), d, P(y_d), d, 0, M, ff, d, EPI_NONE | FLAGS, S))
@@ -67,6 +73,9 @@ def main():
         ns = lib.vlg_linear_wgrad_slabs_for(M, n, k, FLAGS)
         add("gemm wgrad %-4s (%d slabs)" % (nm, ns), fl(n, k), "F", lambda n=n, k=k, dy=dy, xx=xx: hip.call("vlg_linear_wgrad", P(dy), n, P(xx), k, P(slabs), n * k + n, slabs.numel(), M, n, k, FLAGS, S))
         add("reduce wgrad %-4s" % nm, 4.0 * (n * k + n) * (ns + 1), "B", lambda n=n, k=k, ns=ns: hip.call("vlg_reduce_slabs", P(slabs), n * k + n, ns, P(red_dst), n * k + n, S))
+    if not a.bf16:
+        ns = lib.vlg_linear_wgrad_slabs_for(M, d, ff, 0)
+        add("gemm wgrad ff2 (gelu on load)", fl(d, ff), "F", lambda: hip.call("vlg_linear_wgrad", P(x_d), d, P(x_ff), ff, P(slabs), d * ff + d, slabs.numel(), M, d, ff, EPI_ACT_GELU, S))
     add("attention fwd", 16.0 * M * d, "B", lambda: hip.call("vlg_attention_fwd", P(x_3d), P(y_d), B * N, T, d, S))
     add("attention bwd", 28.0 * M * d, "B", lambda: hip.call("vlg_attention_bwd", P(x_3d), P(x_d), P(y_3d), B * N, T, d, S))
     add("layernorm fwd", 8.0 * M * d, "B", lambda: hip.call("vlg_layernorm_fwd", P(x_d), P(g), P(g), P(y_d), P(stats[0]), P(stats[1]), M, d, 1e-5, S))

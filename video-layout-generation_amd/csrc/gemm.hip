@@ -13,10 +13,15 @@
 // the contraction order inside a chunk is free).
 // Block = 256 threads = 4 waves; 128x128 tile => each wave owns 64x64 = 2x2 MFMA tiles
 // (64 accumulator VGPRs).  Staging is global -> VGPR -> LDS, double-buffered in LDS and one tile
-// deep in registers: tile kt+1 is loaded from global during tile kt-1's second half, written to the
-// idle LDS buffer in the MIDDLE of tile kt's MFMAs (behind a wait that is already satisfied), and
-// the loads for tile kt+2 are issued right after - so an iteration ends in a bare barrier with no
-// vmcnt wait and no ds_write burst on the critical path (+5-6 % over load-top / write-bottom).
+// deep in registers: tile kt+1 is loaded from global one iteration ahead, written to the idle LDS
+// buffer BETWEEN the MFMAs of one chunk of tile kt (one ds_write_b128 / global_load_dwordx4 behind
+// each MFMA, pinned with sched_group_barrier), so staging never stops the matrix pipe.
+// The main loop is scheduled by hand (round 2; +5-7 % on every shape, asymptote 140 TFLOP/s = 89 %):
+//   - fragment reads are double-buffered in registers: chunk s+1's LDS reads are issued before chunk
+//     s's 16 MFMAs (hipcc alone reads two registers at a time behind an s_waitcnt every 2-4 MFMAs);
+//   - the steady-state iteration is one basic block (the last two iterations are peeled);
+//   - the iteration's one barrier sits in FRONT of the last chunk's MFMAs and the next tile's first
+//     fragments are read behind it, under those MFMAs.
 // BK (contraction depth per tile) is a template parameter: 32 -> 73.7 KB LDS, 2 blocks / CU;
 // 16 -> 41 KB, 3 blocks / CU.  blockIdx is remapped so tiles sharing an A panel sit on one XCD (L2).
 // Interior blocks take an unguarded instantiation of the main loop; edge blocks clamp + select.
@@ -27,6 +32,20 @@
 
 #include "gemm_tile.h"
 
+// keeps the hand-placed order "next chunk's LDS reads, then this chunk's MFMAs" (see ldfrag below); VLG_NO_SCHED_FENCE
+// builds the loop without it (A/B switch for tools/kernel_bench.py)
+// internal template bits on top of the public VLG_EPI_* ones: the operand named passes through GELU on its way to LDS
+// (VLG_EPI_ACT_GELU: the FFN hidden activation is never stored - the second projection and its weight gradient
+// recompute it from the pre-activation while they stage it, in the shadow of their own MFMAs)
+#define GEMM_A_GELU (1 << 20)
+#define GEMM_B_GELU (1 << 21)
+__device__ __forceinline__ float4 gelu4(float4 v) { return make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w)); }
+
+#ifdef VLG_NO_SCHED_FENCE
+#define VLG_SCHED_FENCE()
+#else
+#define VLG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
@@ -97,12 +116,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     if (g.clock_probe) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     float4 ra[TA::NV], rb[TB::NV];
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
-    auto chunk = [&](const float* as, const float* bs, int s) {
-        float a[TM][4], b[TN][4];
+    auto act = [&](float4 (&xa)[TA::NV], float4 (&xb)[TB::NV]) {
+        if constexpr ((EPI & GEMM_A_GELU) != 0) {
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) xa[i] = gelu4(xa[i]);
+        }
+        if constexpr ((EPI & GEMM_B_GELU) != 0) {
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) xb[i] = gelu4(xb[i]);
+        }
+    };
+    // Fragment reads are software-pipelined by hand: the reads of chunk s+1 are issued BEFORE the 16 MFMAs of chunk s, into a
+    // second register set, so a wave never waits on LDS between MFMAs.  Left to itself hipcc re-reads two registers at
+    // a time with an s_waitcnt lgkmcnt(0) in front of every 2-4 MFMAs: each wave then idles ~30 % of the time and the
+    // two waves of a SIMD idle together often enough to cost ~10 % of the matrix pipe.
+    auto ldfrag = [&](float (&a)[TM][4], float (&b)[TN][4], const float* as, const float* bs, int s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) TA::frag(a[i], as, (wm * TM + i) * 32 + l31, s, h);
 #pragma unroll
         for (int j = 0; j < TN; ++j) TB::frag(b[j], bs, (wn * TN + j) * 32 + l31, s, h);
+    };
+    auto mma = [&](const float (&a)[TM][4], const float (&b)[TN][4]) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -121,31 +155,72 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
             TA::template gload<GUARD>(xa, gA, g.lda, m0, g.M, k0, kend, tid);
             TB::template gload<GUARD>(xb, gB, g.ldb, n0, g.N, k0, kend, tid);
         };
-        auto iter = [&](int kt, float4 (&xa)[TA::NV], float4 (&xb)[TB::NV]) {
+        // STORE / LOAD / NEXT are compile-time so the steady-state iteration is ONE basic block: the compiler can then spread
+        // the staging instructions (8 ds_write_b128, 8 global_load_dwordx4, address arithmetic) between the MFMAs instead
+        // of issuing them as a blob with the matrix pipe idle; the last two iterations are peeled.
+        // The iteration's ONE barrier sits in front of the LAST chunk's MFMAs, not behind them: by then every wave has
+        // its last fragments of this tile in registers and has finished writing the next tile (staged during chunk SS), so
+        // behind the barrier the next tile's first fragments are read while the last chunk's 16 MFMAs run - a wave
+        // leaves the barrier with matrix work in hand instead of an LDS round trip.
+        constexpr int SS = NCH / 2 - 1;          // chunk whose MFMAs cover the staging traffic
+        float fa[2][TM][4], fb[2][TN][4];        // fragment sets: chunk s lives in set s & 1 (NCH is even)
+        auto iter = [&](int kt, float4 (&xa)[TA::NV], float4 (&xb)[TB::NV], auto store_tag, auto load_tag, auto next_tag) {
+            constexpr bool STORE = decltype(store_tag)::value, LOAD = decltype(load_tag)::value, NEXT = decltype(next_tag)::value;
             const int cur = kt & 1;
             const float* as = As0 + cur * TA::FLOATS;
             const float* bs = Bs0 + cur * TB::FLOATS;
 #pragma unroll
-            for (int s = 0; s < NCH / 2; ++s) chunk(as, bs, s);
-            if (kt + 1 < nk) {
-                if constexpr (COLSUM) colsum(xa);
-                TA::sstore(xa, As0 + (cur ^ 1) * TA::FLOATS, tid);
-                TB::sstore(xb, Bs0 + (cur ^ 1) * TB::FLOATS, tid);
-            }
-            if (kt + 1 + DEPTH < nk) load(xa, xb, kt + 1 + DEPTH);
+            for (int s = 0; s < NCH; ++s) {
+                if (s + 1 < NCH) ldfrag(fa[(s + 1) & 1], fb[(s + 1) & 1], as, bs, s + 1);
+                if (s == NCH - 1 && NEXT) {
+                    __syncthreads();
+                    ldfrag(fa[0], fb[0], As0 + (cur ^ 1) * TA::FLOATS, Bs0 + (cur ^ 1) * TB::FLOATS, 0);
+                }
+                VLG_SCHED_FENCE();                 // reads above, MFMAs below; the staging code may mix with the MFMAs
+                if (s == SS) {
+                    if constexpr (STORE) {
+                        if constexpr (COLSUM) colsum(xa);
+                        act(xa, xb);
+                        TA::sstore(xa, As0 + (cur ^ 1) * TA::FLOATS, tid);
+                        TB::sstore(xb, Bs0 + (cur ^ 1) * TB::FLOATS, tid);
+                    }
+                    if constexpr (LOAD) load(xa, xb, kt + 1 + DEPTH);
+                }
+                mma(fa[s & 1], fb[s & 1]);
+                if (s == SS && (STORE || LOAD)) {
+                    // pin the interleave: one LDS write (then one global load) behind each MFMA of this chunk, so the
+                    // matrix pipe keeps issuing while the tile is staged (hipcc left alone emits the writes as one blob)
+                    constexpr int N_MFMA = 4 * TM * TN, N_ST = (STORE ? TA::NV + TB::NV : 0), N_LD = (LOAD ? TA::NV + TB::NV : 0);
+                    constexpr int PER = (N_ST + N_LD + N_MFMA - 1) / N_MFMA;
 #pragma unroll
-            for (int s = NCH / 2; s < NCH; ++s) chunk(as, bs, s);
-            __syncthreads();
+                    for (int i = 0; i < N_MFMA; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                        for (int q = 0; q < PER; ++q) {
+                            const int slot = i * PER + q;
+                            if (slot < N_ST) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                            else if (slot < N_ST + N_LD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
+                    }
+                }
+            }
         };
+        static_assert(NCH >= 2 && NCH % 2 == 0, "fragment sets alternate by chunk parity");
         if (nk > 0) {
             load(ra, rb, 0);
             if constexpr (COLSUM) colsum(ra);
+            act(ra, rb);
             TA::sstore(ra, As0, tid);
             TB::sstore(rb, Bs0, tid);
         }
         if (nk > 1) load(ra, rb, 1);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) iter(kt, ra, rb);
+        if (nk > 0) ldfrag(fa[0], fb[0], As0, Bs0, 0);
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) iter(kt, ra, rb, std::true_type{}, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { iter(kt, ra, rb, std::true_type{}, std::false_type{}, std::true_type{}); ++kt; }
+        if (kt < nk) iter(kt, ra, rb, std::false_type{}, std::false_type{}, std::false_type{});
+        __syncthreads();                           // the tiles are dead from here on (the COLSUM epilogue reuses the LDS)
     };
     // interior blocks (every tile fully inside both operands) take the unguarded instantiation
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) % BK) == 0);
@@ -282,10 +357,17 @@ extern "C" int vlg_linear_fwd(const void* A, int lda, const void* W, int ldw, co
     if ((epilogue & (VLG_EPI_RESID | VLG_EPI_DGELU)) && !aux_in) return VLG_ERR_SHAPE;
     if ((epilogue & VLG_EPI_GELU) && !aux_out) return VLG_ERR_SHAPE;
     const bool narrow = N <= 32;
+    const bool act_gelu = (epilogue & VLG_EPI_ACT_GELU) != 0;
+    epilogue &= ~VLG_EPI_ACT_GELU;
+    if (act_gelu && (bf16 || split3)) return VLG_ERR_SHAPE;      // native fp32 path only
     if (io != 0 && !bf16) return VLG_ERR_SHAPE;      // bf16 activation storage exists for the bf16 MFMA mode only
     if (((io & 1) && (lda & 7)) || ((io & 2) && (ldw & 7))) return VLG_ERR_ALIGN;
     if (bf16) return vlg_gemm16_fwd(g, epilogue, io, s);
     if (split3) return vlg_gemm_split_fwd(g, epilogue, s);
+    if (act_gelu) {                                   // A = gelu(stored pre-activation): the FFN's second projection
+        if (epilogue != (VLG_EPI_BIAS | VLG_EPI_RESID) || narrow) return VLG_ERR_SHAPE;
+        return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID | GEMM_A_GELU, false>(g, s);
+    }
     switch (epilogue) {
         case VLG_EPI_BIAS:
             return narrow ? launch_gemm<128, 32, true, true, VLG_EPI_BIAS, false>(g, s)
@@ -373,8 +455,10 @@ extern "C" int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
     const int io = gemm_io_bits(flags);
     if (io != 0 && !bf16) return VLG_ERR_SHAPE;
     if (((io & 1) && (ldy & 7)) || ((io & 2) && (ldx & 7))) return VLG_ERR_ALIGN;
-    if (bf16) return vlg_gemm16_wgrad(g, io, s);
-    if (flags & VLG_EPI_SPLIT3) return io == 0 ? vlg_gemm_split_wgrad(g, s) : VLG_ERR_SHAPE;
+    if (bf16) return (flags & VLG_EPI_ACT_GELU) ? VLG_ERR_SHAPE : vlg_gemm16_wgrad(g, io, s);
+    if (flags & VLG_EPI_SPLIT3) return (io == 0 && !(flags & VLG_EPI_ACT_GELU)) ? vlg_gemm_split_wgrad(g, s) : VLG_ERR_SHAPE;
+    if (flags & VLG_EPI_ACT_GELU)                     // X = gelu(stored pre-activation): weight gradient of the FFN's second projection
+        return N <= 32 ? VLG_ERR_SHAPE : launch_gemm<128, 128, false, false, GEMM_B_GELU, true>(g, s);
     return N <= 32 ? launch_gemm<32, 128, false, false, VLG_EPI_NONE, true>(g, s)
                    : launch_gemm<128, 128, false, false, VLG_EPI_NONE, true>(g, s);
 }

@@ -16,13 +16,14 @@ Row order of every (M, .) activation is the internal  m = (b*N + n)*T + t.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
 
 from . import hip
-from .hip import (EPI_A_BF16, EPI_B_BF16, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_OUT_BF16, EPI_RESID, call,
-                  ptr)
+from .hip import (EPI_A_BF16, EPI_ACT_GELU, EPI_B_BF16, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_OUT_BF16, EPI_RESID,
+                  call, ptr)
 from .spec import (ADAM_BETA1, ADAM_BETA2, ADAM_EPS, ADAM_LR, BOX_DIM, IOU_EPS, LN_EPS, LOSS_W_CE,
                    LOSS_W_REG, LOSS_W_STRUCT, SMOOTH_L1_BETA, LayoutConfig, param_layout)
 
@@ -76,6 +77,9 @@ class LayoutEngine:
         self.precision = precision
         self.gemm_flags = {"fp32": 0, "fp32x3": hip.EPI_SPLIT3}.get(precision, hip.EPI_BF16)
         self.bf16_store = precision == "bf16"
+        # optional (native fp32 only): gelu(u) is never stored - the FFN's first projection writes the pre-activation u
+        # only and the second projection / its weight gradient apply GELU while staging their operand (VLG_EPI_ACT_GELU)
+        self.gelu_on_load = False      # measured slower end to end (GEMM notes): the recomputation is not hidden
         self._sfx = "_bf16" if self.bf16_store else ""
         hip.load()                                   # fail loudly before touching the GPU
         if device.type != "cuda":
@@ -177,7 +181,7 @@ class LayoutEngine:
         self.xmid = torch.empty(L, M, d, **f32)
         self.h2 = torch.empty(L, M, d, **act)
         self.u = torch.empty(L, M, ff, **act)             # FFN pre-activation
-        self.gl = torch.empty(L, M, ff, **act)            # gelu(u)
+        self.gl = None if self.gelu_on_load else torch.empty(L, M, ff, **act)            # gelu(u)
         self.stats = torch.empty(2 * L + 1, 2, M, **f32)  # mean / rstd of every layer-norm
         self.xf = torch.empty(M, d, **act)
         self.out = torch.empty(M, cfg.n_out, **f32)
@@ -192,7 +196,14 @@ class LayoutEngine:
         need = [lib.vlg_embed_bwd_slabs() * emb_len, lib.vlg_layernorm_bwd_slabs(M) * 2 * d]
         for (n, k) in ((3 * d, d), (d, d), (ff, d), (d, ff), (cfg.n_out, d)):
             need.append(lib.vlg_linear_wgrad_slabs_for(M, n, k, self.gemm_flags) * (n * k + n))
-        self.slabs = torch.empty(max(need), **f32)
+        self.slabs = torch.empty(max(need[:2]), **f32)          # partial sums written on the main stream (layer-norm, embedding)
+        self.slabs_w = torch.empty(max(need[2:]), **f32)        # weight-gradient partials (written on the side stream in backward)
+        # option: backward can run the weight gradients on a second HIP stream, concurrently with the data-gradient chain
+        # (see backward).  Measured -1.7 % step time at the metric shape (6.12 -> 6.02 ms): a 512-block launch takes every
+        # CU slot, so the other stream's kernel only overlaps its tail.  OFF by default: with two kernels sharing the chip
+        # a kernel's own duration no longer says anything about that kernel (bench.py's per-kernel roofline).
+        self.side = torch.cuda.Stream(device=self.device)
+        self.overlap_wgrad = os.environ.get("VLG_OVERLAP_WGRAD", "0") == "1"
 
     # --------------------------------------------------------------------- helpers
     @staticmethod
@@ -228,17 +239,19 @@ class LayoutEngine:
         self._timed("gemm_dgrad", 2.0 * M * N * K, "vlg_linear_dgrad", ptr(dy), N, ptr(w), K, ptr(dx), K,
                     ptr(aux_in), M, N, K, flags, self._stream(), nbytes=nb)
 
-    def _wgrad(self, dy, x, wname, M, N, K):
-        """grad[w | b] = (dy^T . x | colsum dy): split partials -> slab arena -> flat gradient."""
+    def _wgrad(self, dy, x, wname, M, N, K, extra=0):
+        """grad[w | b] = (dy^T . x | colsum dy): split partials -> slab arena -> flat gradient.  extra = EPI_ACT_GELU: x holds
+        pre-activations, the kernel applies GELU while staging it.  Runs on the CURRENT stream (backward makes that the
+        side stream)."""
         lib = hip.load()
         stride = N * K + N
         n_slabs = lib.vlg_linear_wgrad_slabs_for(M, N, K, self.gemm_flags)
         s = self._stream()
         self._timed("gemm_wgrad" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_wgrad", ptr(dy), N, ptr(x),
-                    K, ptr(self.slabs), stride, self.slabs.numel(), M, N, K, self.gemm_flags | self._storage_bits(dy, x), s,
+                    K, ptr(self.slabs_w), stride, self.slabs_w.numel(), M, N, K, self.gemm_flags | self._storage_bits(dy, x) | extra, s,
                     nbytes=dy.element_size() * M * N + x.element_size() * M * K + 4.0 * n_slabs * stride)
         off = self.layout[wname][0]
-        call("vlg_reduce_slabs", ptr(self.slabs), stride, n_slabs, self.grads.data_ptr() + 4 * off, stride, s)
+        call("vlg_reduce_slabs", ptr(self.slabs_w), stride, n_slabs, self.grads.data_ptr() + 4 * off, stride, s)
 
     def _ln_fwd(self, x, gname, y, stat, M):
         d = self.cfg.d
@@ -290,10 +303,15 @@ class LayoutEngine:
             self._linear(self.att[l], self.pw(pre + "proj_w"), self.p(pre + "proj_b"), self.xmid[l], M, d, d,
                          EPI_BIAS | EPI_RESID, aux_in=x)
             self._ln_fwd(self.xmid[l], pre + "ln2_g", self.h2[l], self.stats[2 * l + 1], M)
-            self._linear(self.h2[l], self.pw(pre + "ff1_w"), self.p(pre + "ff1_b"), self.gl[l], M, ff, d,
-                         EPI_BIAS | EPI_GELU, aux_out=self.u[l])
-            self._linear(self.gl[l], self.pw(pre + "ff2_w"), self.p(pre + "ff2_b"), self.x[l + 1], M, d, ff,
-                         EPI_BIAS | EPI_RESID, aux_in=self.xmid[l])
+            if self.gelu_on_load:
+                self._linear(self.h2[l], self.pw(pre + "ff1_w"), self.p(pre + "ff1_b"), self.u[l], M, ff, d, EPI_BIAS)
+                self._linear(self.u[l], self.pw(pre + "ff2_w"), self.p(pre + "ff2_b"), self.x[l + 1], M, d, ff,
+                             EPI_BIAS | EPI_RESID | EPI_ACT_GELU, aux_in=self.xmid[l])
+            else:
+                self._linear(self.h2[l], self.pw(pre + "ff1_w"), self.p(pre + "ff1_b"), self.gl[l], M, ff, d,
+                             EPI_BIAS | EPI_GELU, aux_out=self.u[l])
+                self._linear(self.gl[l], self.pw(pre + "ff2_w"), self.p(pre + "ff2_b"), self.x[l + 1], M, d, ff,
+                             EPI_BIAS | EPI_RESID, aux_in=self.xmid[l])
         L = cfg.n_layers
         self._ln_fwd(self.x[L], "lnf_g", self.xf, self.stats[2 * L], M)
         self._linear(self.xf, self.pw("head_w"), self.p("head_b"), self.out, M, cfg.n_out, d, EPI_BIAS)
@@ -306,38 +324,89 @@ class LayoutEngine:
     def backward(self, batch: Dict[str, torch.Tensor], reducer=None) -> None:
         """Fills self.grads (every element overwritten) from the state forward() left.  `reducer`
         (vlg.dp.GradReducer) is told as soon as each contiguous gradient bucket is complete so its
-        all-reduce overlaps the rest of backward."""
+        all-reduce overlaps the rest of backward.
+
+        Two HIP streams.  The data-gradient chain (dgrad GEMMs, attention / layer-norm backward) stays on the caller's
+        stream; every weight gradient (+ its slab reduction) is launched on `self.side` as soon as its dY exists and runs
+        CONCURRENTLY with the chain.  Each GEMM launch leaves the matrix pipes idle while its blocks load their first tiles
+        and drain their stores (all blocks of a launch do that in step: 10-25 % of a K = 256 launch), and the
+        bandwidth-bound kernels of the chain leave them idle altogether; blocks of the other stream's kernel fill those
+        gaps.  Ordering is by events: a side kernel waits for the producer of its dY, and the chain waits before it
+        overwrites a buffer a side kernel still reads (du, dqkv, dx) and before a bucket is handed to the reducer."""
         cfg, d, ff = self.cfg, self.cfg.d, self.cfg.d_ff
         B, T, N, M = self._shape
-        s = self._stream()
+        main = torch.cuda.current_stream(self.device)
+        side = self.side if self.overlap_wgrad else main
+        s = main.cuda_stream
         L = cfg.n_layers
-        self._wgrad(self.dout, self.xf, "head_w", M, cfg.n_out, d)
+        last_read: Dict[str, torch.cuda.Event] = {}
+
+        def on_side(reads, fn):
+            """launch fn on the side stream once everything enqueued on the main stream so far is done; remember when the
+            buffers it reads become free again"""
+            if side is main:
+                fn()
+                return
+            e = torch.cuda.Event()
+            e.record(main)
+            side.wait_event(e)
+            with torch.cuda.stream(side):
+                fn()
+                done = torch.cuda.Event()
+                done.record(side)
+            for name in reads:
+                last_read[name] = done
+
+        def before_write(*names):
+            for name in names:
+                e = last_read.pop(name, None)
+                if e is not None:
+                    main.wait_event(e)
+
+        def join():
+            if side is not main:
+                e = torch.cuda.Event()
+                e.record(side)
+                main.wait_event(e)
+                last_read.clear()
+
+        on_side(("dout",), lambda: self._wgrad(self.dout, self.xf, "head_w", M, cfg.n_out, d))
         self._dgrad(self.dout, self.pw("head_w"), self.dh, M, cfg.n_out, d)
         self._ln_bwd(self.dh, self.x[L], self.stats[2 * L], "lnf_g", None, self.dx, M)
         if reducer is not None:
+            join()
             reducer.ready("head")
         for l in reversed(range(L)):
             pre = "l%d." % l
             # FFN:  x_out = xmid + W2 gelu(W1 h2 + b1) + b2
-            self._wgrad(self.dx, self.gl[l], pre + "ff2_w", M, d, ff)
+            if self.gelu_on_load:
+                on_side(("dx",), lambda: self._wgrad(self.dx, self.u[l], pre + "ff2_w", M, d, ff, extra=EPI_ACT_GELU))
+            else:
+                on_side(("dx",), lambda: self._wgrad(self.dx, self.gl[l], pre + "ff2_w", M, d, ff))
+            before_write("du")
             self._dgrad(self.dx, self.pw(pre + "ff2_w"), self.du, M, d, ff, EPI_DGELU, aux_in=self.u[l])
-            self._wgrad(self.du, self.h2[l], pre + "ff1_w", M, ff, d)
+            on_side(("du",), lambda: self._wgrad(self.du, self.h2[l], pre + "ff1_w", M, ff, d))
             self._dgrad(self.du, self.pw(pre + "ff1_w"), self.dh, M, ff, d)
+            before_write("dx")
             self._ln_bwd(self.dh, self.xmid[l], self.stats[2 * l + 1], pre + "ln2_g", self.dx, self.dx, M)
             # attention:  xmid = x + Wo attn(Wqkv h1 + b) + bo
-            self._wgrad(self.dx, self.att[l], pre + "proj_w", M, d, d)
+            on_side(("dx",), lambda: self._wgrad(self.dx, self.att[l], pre + "proj_w", M, d, d))
             self._dgrad(self.dx, self.pw(pre + "proj_w"), self.dh, M, d, d)
+            before_write("dqkv")
             call("vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s)
-            self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d)
+            on_side(("dqkv",), lambda: self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d))
             self._dgrad(self.dqkv, self.pw(pre + "qkv_w"), self.dh, M, 3 * d, d)
+            before_write("dx")
             self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)
             if reducer is not None:
+                join()
                 reducer.ready("l%d" % l)
         lib = hip.load()
         emb_len = self.layout["l0.ln1_g"][0]
         call("vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.slabs),
              emb_len, self.slabs.numel(), B, T, N, d, cfg.vocab, s)
         call("vlg_reduce_slabs", ptr(self.slabs), emb_len, lib.vlg_embed_bwd_slabs(), ptr(self.grads), emb_len, s)
+        join()
         if reducer is not None:
             reducer.ready("embed")
 

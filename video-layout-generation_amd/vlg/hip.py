@@ -11,10 +11,12 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvlg_hip.so")
+# VLG_HIP_LIB: development override (A/B runs of two builds in one gpurun call, tools/kernel_bench.py); still no fallback
+LIB_PATH = os.environ.get("VLG_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libvlg_hip.so")
 
 EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_BF16 = 0, 1, 2, 4, 8, 16
 EPI_A_BF16, EPI_B_BF16, EPI_OUT_BF16, EPI_SPLIT3 = 32, 64, 128, 256      # bf16 activation storage (include/vlg_hip.h)
+EPI_ACT_GELU = 512                                                       # activation operand = gelu(stored), applied on load
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 
