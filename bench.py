@@ -9,13 +9,21 @@ A step = forward + fused losses + backward + (bucketed RCCL gradient all-reduce)
 batch of synthetic clips already resident in HBM.  Workload at every N: (B,T,N_slots)=(32,16,64),
 d=256 per GPU (weak scaling: per-GPU clips fixed, global batch = 32 * N).  One JSON line on rank 0.
 
-Extra objects on the line:
-  roofline      the dominant kernel (by summed device time inside the timed steps, measured with
-                HIP events on the launch stream): algorithmic FLOP per launch / average launch
-                duration vs the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
-  cpu_baseline  the CPU oracle's identical step (torch-CPU, all host cores) on a bounded sample
+Objects on the line besides the contract's fields:
+  roofline        the dominant kernel (largest summed device time of the step: the weight-gradient GEMM): algorithmic
+                  FLOP per launch / its average launch duration, from HIP events recorded on the launch stream INSIDE
+                  the timed steps (every 4th step), vs the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
+                  `share_of_step` = launches per step x that duration / ms_per_step; `traffic` = HBM bytes per launch from
+                  the committed PMC pass (profiles/pmc_traffic.json) IF that file was taken from these kernel sources
+                  (source hash), else null; `step` = the whole step against the same peak
+  roofline_hbm    the bandwidth-bound kernels north_star names (embedding, layer-norm, attention, losses, Adam): algorithmic
+                  bytes / event time vs 8 TB/s, from an untimed extra pass with every launch bracketed
+  cpu_baseline    the CPU oracle's identical step (torch-CPU, host threads stated) on a bounded sample of the SAME batch
+  bf16_projections / f32x3_projections   the two other projection modes (informational; `value` stays native fp32)
+  strong_scaling_shard   the per-GPU share of the reference's GLOBAL batch semantics (src/trainer.py:148: 32 // 8 = 4 clips)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,40 +38,58 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
-DOMINANT = "gemm_wgrad"          # largest share of device time (profiles/r01_*_kernel_stats.csv)
+DOMINANT = "gemm_wgrad"          # largest share of device time (profiles/r0*_kernel_stats.csv)
+GEMM_FAMILIES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_head")
 KERNEL_OF_FAMILY = {             # rocprofv3 kernel names (profiles/) for each timed family
-    "gemm_fwd": "gemm_f32_kernel<128,128,32,true,true,*,false>",
-    "gemm_dgrad": "gemm_f32_kernel<128,128,32,true,false,*,false>",
+    "gemm_fwd": "gemm_f32_kernel<128,128,32|16,true,true,*,false>",
+    "gemm_dgrad": "gemm_f32_kernel<128,128,32|16,true,false,*,false>",
     "gemm_wgrad": "gemm_f32_kernel<128,128,32,false,false,0,true>",
     "gemm_head": "gemm_f32_kernel<128,32,32,..>/<32,128,32,..>",
+    "embed_fwd": "embed_fwd_kernel", "embed_bwd": "embed_bwd_kernel", "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel",
+    "attn_fwd": "attn16_fwd_kernel", "attn_bwd": "attn16_bwd_kernel", "loss": "layout_loss_kernel", "adam": "adam_kernel",
 }
 KERNEL_OF_FAMILY_X3 = {          # --dtype f32x3 (csrc/gemm_split.hip)
-    "gemm_fwd": "gemm_split_kernel<128,128,true,true,*,false>",
-    "gemm_dgrad": "gemm_split_kernel<128,128,true,false,*,false>",
     "gemm_wgrad": "gemm_split_kernel<128,128,false,false,0,true>",
-    "gemm_head": "gemm_split_kernel<128,32,..>/<32,128,..>",
 }
 KERNEL_OF_FAMILY_BF16 = {        # --dtype bf16: bf16 LDS tiles, 64-deep, IO = storage bits (csrc/gemm_bf16.hip)
-    "gemm_fwd": "gemm_bf16_kernel<128,128,true,true,*,false,IO>",
-    "gemm_dgrad": "gemm_bf16_kernel<128,128,true,false,*,false,IO>",
     "gemm_wgrad": "gemm_bf16_kernel<128,128,false,false,0,true,IO>",
-    "gemm_head": "gemm_bf16_kernel<128,32,..>/<32,128,..>",
 }
+TRAFFIC_SOURCES = ("gemm.hip", "gemm_tile.h", "common.h")
 
 
-def cpu_baseline(cfg, budget_s: float = 12.0):
-    """Times the CPU oracle (the only CPU implementation of this step: the reference has none)
-    on a bounded sample: same T, N, d, depth; fewer clips per step so it fits the budget."""
+def kernel_source_hash() -> str:
+    """sha256 (16 hex) of the sources the dominant kernel is built from: ties profiles/pmc_traffic.json to a build."""
+    h = hashlib.sha256()
+    for name in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, "video-layout-generation_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(family: str):
+    """HBM bytes per launch of `family` from the committed PMC pass, or None when that pass predates the kernel sources."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    if rec.get("source_sha16") != kernel_source_hash():
+        return None
+    return rec.get(family)
+
+
+def cpu_baseline(cfg, steps: int = 3):
+    """Times the CPU oracle (the only CPU implementation of this step: the reference has none) on the SAME batch shape
+    (B clips per step), a bounded number of steps."""
     from oracle import layout_spec as O
     from vlg.spec import param_shapes
     # the GPU box gives a one-GPU job a 16-core share; more threads than that only oversubscribes
     threads = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
-    B = min(cfg.B, 8)
     p = O.init_params(param_shapes(cfg), seed=1024)
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(x) for k, x in p.items()}
-    batch = O.synthetic_batch(B, cfg.T, cfg.N, seed=1024)
+    batch = O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=1024)
 
     def step(i):
         _, g = O.loss_and_grads(p, batch, cfg.n_layers)
@@ -73,15 +99,24 @@ def cpu_baseline(cfg, budget_s: float = 12.0):
     step(1)                                   # warm-up
     t0 = time.perf_counter()
     n = 0
-    while True:
+    while n < steps:
         step(n + 2)
         n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 400:
+        if time.perf_counter() - t0 > 40.0:
             break
-    return {"value": round(B * n / el, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+    el = time.perf_counter() - t0
+    return {"value": round(cfg.B * n / el, 3), "unit": "clips/s", "cores": threads, "kind": "port", "clips_per_step": cfg.B,
             "sample": "%d steps of %d clips (T=%d,N=%d,d=%d,L=%d), torch-CPU oracle fwd+bwd+Adam, %.1f s"
-                      % (n, B, cfg.T, cfg.N, cfg.d, cfg.n_layers, el)}
+                      % (n, cfg.B, cfg.T, cfg.N, cfg.d, cfg.n_layers, el)}
+
+
+def timed_steps(step_fn, n: int) -> float:
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step_fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
 
 
 def main():
@@ -101,6 +136,7 @@ def main():
                     help="replay the step from one captured hipGraph (single GPU; same kernels, one host call per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (other modes, B=4 shard)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,6 +145,12 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    if os.environ.get("VLG_BENCH_ONE_DEVICE", "0") == "1":
+        # rehearsal with N processes on ONE device: each HIP process opens 4 hardware queues by default (+ gloo's copy
+        # streams); beyond the device's hardware queue slots the driver time-slices the run list and a 6 ms step takes 69 s
+        # (measured at 4 ranks: 69 235 ms / step with the default, 36 ms with 2 queues per process - DESIGN.md (e)).
+        # Read by the HIP runtime when it starts, so it is set before the first HIP call.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path for the product")
     if os.environ.get("VLG_BENCH_ONE_DEVICE", "0") == "1":
@@ -131,13 +173,15 @@ def main():
     from vlg.spec import LayoutConfig, SEED, step_flops
 
     cfg = LayoutConfig(B=args.B, T=args.T, N=args.N, d=args.d, n_layers=args.layers)
-    eng = LayoutEngine(cfg, dev, seed=SEED, precision={"f32": "fp32", "f32x3": "fp32x3", "bf16": "bf16"}[args.dtype])   # same seed on every rank (main.py:57-60)
+    precision = {"f32": "fp32", "f32x3": "fp32x3", "bf16": "bf16"}[args.dtype]
+    eng = LayoutEngine(cfg, dev, seed=SEED, precision=precision)   # same seed on every rank (main.py:57-60)
     batch = to_device(synthetic_clips(cfg.B, cfg.T, cfg.N, seed=SEED + rank), dev)   # each rank its own clips
     reducer = None
     force = os.environ.get("VLG_FORCE_COMM", "0") == "1"      # 1-GPU rehearsal of the RCCL path (torchrun, world size 1)
     if world > 1 or (distributed and force):
         reducer = GradReducer(eng.grads_ext, bucket_ranges(eng.layout, eng.n_params, cfg.n_layers),
                               always_communicate=force)
+    trace = os.environ.get("VLG_BENCH_TRACE", "0") == "1"     # host timestamps per step (rehearsal diagnostics)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -165,11 +209,21 @@ def main():
     # every rocprof summary in profiles/) is bracketed with events, and only on every 4th step (16 launches each):
     # an event pair around each of its launches costs ~2 % of `value`, around all ~70 GEMM launches far more.
     ktimer = None if (args.no_kernel_timing or args.graph) else KernelTimer(only=(DOMINANT,))   # events are not part of a replayed graph
+    sampled_steps = 0
     sync_all()
     t0 = time.perf_counter()
     for it in range(args.steps):
-        eng.timer = ktimer if it % 4 == 0 else None
+        sample = ktimer is not None and it % 4 == 0
+        eng.timer = ktimer if sample else None
+        sampled_steps += int(sample)
+        if trace and rank == 0:
+            h0 = time.perf_counter()
         step_fn()
+        if trace and rank == 0:
+            h1 = time.perf_counter()
+            torch.cuda.synchronize()
+            print("trace step %d: host enqueue %.2f ms, device drained after %.2f ms" % (it, 1e3 * (h1 - h0), 1e3 * (time.perf_counter() - h0)),
+                  file=sys.stderr, flush=True)
     eng.timer = ktimer
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -182,10 +236,11 @@ def main():
     if rank == 0:
         clips = world * cfg.B * args.steps
         fl = step_flops(cfg)
+        ms_per_step = 1e3 * elapsed / args.steps
         line = {
             "metric": "training clips/sec at (B,T,N)=(32,16,64) d=256; 1/2/4/8-GPU scaling",
             "value": round(clips / elapsed, 2), "unit": "clips/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "primed": args.warmup == 0, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "steps": args.steps, "warmup": args.warmup, "primed": args.warmup == 0, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic", "hipgraph": bool(args.graph),
             "config": {"workload": "layout-token training step, (B,T,N)=(%d,%d,%d) clips per GPU, d=%d"
@@ -196,48 +251,56 @@ def main():
                        "step_tflops": round(fl["fwd_bwd"] * args.steps / elapsed / 1e12, 2),
                        "final_loss": [round(x, 5) for x in loss]},
         }
-        roof = None
+        roof, roof_hbm = None, None
         if eng.timer is not None:
-            summ = eng.timer.summary()
-            fam = DOMINANT
-            s = summ[fam]
-            # untimed diagnostic pass: every GEMM family bracketed, to show the dominant one IS dominant
-            # (rank 0 only, so WITHOUT the reducer: a collective here would have no partner on the other ranks)
+            s = eng.timer.summary()[DOMINANT]
+            # untimed diagnostic pass: EVERY launch bracketed (rank 0 only, so WITHOUT the reducer: a collective here
+            # would have no partner on the other ranks)
             eng.timer = KernelTimer()
             for _ in range(2):
                 eng.train_step(batch, None)
             torch.cuda.synchronize()
             allf = eng.timer.summary()
+            eng.timer = None
             achieved = s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f).get(fam)
+            traffic = committed_traffic(DOMINANT) if args.dtype == "f32" else None
             bound, peak, unit = "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+            names = KERNEL_OF_FAMILY
             if args.dtype == "f32x3":
                 # six bf16 MFMAs stand for one fp32 product block: price the ALGORITHMIC flops against the bf16 peak / 6
-                peak = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
-                traffic = None                     # the committed PMC pass was taken in f32 mode
+                peak, names = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), dict(KERNEL_OF_FAMILY, **KERNEL_OF_FAMILY_X3)
             if args.dtype == "bf16":
                 # with 16x faster MFMAs the same kernel is bound by moving its operands: price it against HBM
                 # (algorithmic bytes: both operands once + the slabs written)
                 bound, peak, unit = "hbm", PEAK_HBM_GBS, "GB/s"
                 achieved = s["bytes_per_launch"] / (s["avg_ms"] * 1e-3) / 1e9
-                traffic = None                     # the committed PMC pass was taken in f32 mode
+                names = dict(KERNEL_OF_FAMILY, **KERNEL_OF_FAMILY_BF16)
+            launches_per_step = s["launches"] / max(sampled_steps, 1)
+            step_tflops = fl["fwd_bwd"] / (ms_per_step * 1e-3) / 1e12
             roof = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(s["bytes_per_launch"]),
-                    "kernel": {"bf16": KERNEL_OF_FAMILY_BF16, "f32x3": KERNEL_OF_FAMILY_X3, "f32": KERNEL_OF_FAMILY}[args.dtype][fam], "launches": s["launches"],
+                    "kernel": names[DOMINANT], "launches": s["launches"], "launches_per_step": launches_per_step,
                     "avg_launch_us": round(1e3 * s["avg_ms"], 2),
                     "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
-                    "share_of_step": round(s["total_ms"] / (1e3 * elapsed), 4),
+                    "share_of_step": round(launches_per_step * s["avg_ms"] / ms_per_step, 4),
+                    "kernel_source_sha16": kernel_source_hash(),
+                    "step": {"achieved": round(step_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                             "note": "all %.1f GFLOP of the step / ms_per_step vs the native fp32 MFMA peak" % (fl["fwd_bwd"] / 1e9)},
                     "families_untimed_pass": {k: {"avg_us": round(1e3 * v["avg_ms"], 2), "launches": v["launches"],
                                                   "ms_per_step": round(v["total_ms"] / 2, 3),
                                                   "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 2)}
-                                              for k, v in allf.items()}}
+                                              for k, v in allf.items() if k in GEMM_FAMILIES}}
+            roof_hbm = [{"kernel": KERNEL_OF_FAMILY.get(k, k), "family": k, "bound": "hbm",
+                         "achieved": round(v["bytes_per_launch"] / (v["avg_ms"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(v["bytes_per_launch"] / (v["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                         "algorithmic_bytes_per_launch": int(v["bytes_per_launch"]), "avg_launch_us": round(1e3 * v["avg_ms"], 2),
+                         "launches_per_step": v["launches"] // 2, "ms_per_step": round(v["total_ms"] / 2, 4)}
+                        for k, v in allf.items() if k not in GEMM_FAMILIES]
         line["roofline"] = roof
-        if args.dtype == "f32" and world == 1:
+        line["roofline_hbm"] = roof_hbm
+        if args.dtype == "f32" and world == 1 and not args.no_extras:
             # informational: the same step in the two other projection modes; `value` stays native fp32
             notes = {
                 "bf16": ("bf16_projections",
@@ -254,15 +317,43 @@ def main():
                 e2 = LayoutEngine(cfg, dev, seed=SEED, precision=prec)
                 for _ in range(3):
                     e2.train_step(batch)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(10):
-                    e2.train_step(batch)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 10
+                dt = timed_steps(lambda: e2.train_step(batch), 10)
                 line[key] = {"value": round(cfg.B / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt, 4),
                              "note": note, "final_loss": round(float(e2.loss_out[0]), 5)}
+                if prec == "bf16":
+                    # BASELINE configs[2] asks for HBM GB/s + MFMA utilisation of this mode: the dominant kernel's
+                    # algorithmic bytes / event time, and the step's projection FLOPs against the dense bf16 MFMA peak
+                    e2.timer = KernelTimer()
+                    for _ in range(2):
+                        e2.train_step(batch)
+                    torch.cuda.synchronize()
+                    fam = e2.timer.summary()
+                    e2.timer = None
+                    w = fam[DOMINANT]
+                    line[key]["hbm"] = {"kernel": KERNEL_OF_FAMILY_BF16[DOMINANT], "avg_launch_us": round(1e3 * w["avg_ms"], 2),
+                                        "achieved_gbs": round(w["bytes_per_launch"] / (w["avg_ms"] * 1e-3) / 1e9, 1),
+                                        "frac_of_8000": round(w["bytes_per_launch"] / (w["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                    line[key]["mfma_util"] = {"step_tflops": round(fl["fwd_bwd"] / dt / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                              "frac": round(fl["fwd_bwd"] / dt / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                              "kernel_tflops": round(w["flops_per_launch"] / (w["avg_ms"] * 1e-3) / 1e12, 1)}
+                    line[key]["families"] = {k: {"avg_us": round(1e3 * v["avg_ms"], 2), "gbs": round(v["bytes_per_launch"] / (v["avg_ms"] * 1e-3) / 1e9, 1)}
+                                             for k, v in fam.items()}
                 del e2
+            # the reference's batch semantics are GLOBAL (src/main.py:105-106, src/trainer.py:148: per-GPU = 32 // gpus):
+            # the 8-GPU share of the metric batch is 4 clips per GPU - measurable on one GPU, informational
+            c4 = LayoutConfig(B=max(cfg.B // 8, 1), T=cfg.T, N=cfg.N, d=cfg.d, n_layers=cfg.n_layers)
+            e4 = LayoutEngine(c4, dev, seed=SEED)
+            b4 = to_device(synthetic_clips(c4.B, c4.T, c4.N, seed=SEED), dev)
+            for _ in range(5):
+                e4.train_step(b4)
+            dt = timed_steps(lambda: e4.train_step(b4), 30)
+            f4 = step_flops(c4)
+            line["strong_scaling_shard"] = {
+                "clips_per_gpu": c4.B, "ms_per_step": round(1e3 * dt, 4), "clips_per_s_one_gpu": round(c4.B / dt, 1),
+                "step_tflops": round(f4["fwd_bwd"] / dt / 1e12, 2),
+                "note": "one rank's share if the GLOBAL batch stayed 32 on 8 GPUs (reference semantics); no communication here: "
+                        "the 12.7 MB gradient all-reduce would have to hide inside this step time"}
+            del e4
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         else:

@@ -255,16 +255,18 @@ class LayoutEngine:
 
     def _ln_fwd(self, x, gname, y, stat, M):
         d = self.cfg.d
-        call("vlg_layernorm_fwd_bf16" if y.dtype == torch.bfloat16 else "vlg_layernorm_fwd", ptr(x), ptr(self.p(gname)), ptr(self.p(gname[:-1] + "b")), ptr(y), ptr(stat[0]),
-             ptr(stat[1]), M, d, LN_EPS, self._stream())
+        self._timed("ln_fwd", 0.0, "vlg_layernorm_fwd_bf16" if y.dtype == torch.bfloat16 else "vlg_layernorm_fwd", ptr(x), ptr(self.p(gname)),
+                    ptr(self.p(gname[:-1] + "b")), ptr(y), ptr(stat[0]), ptr(stat[1]), M, d, LN_EPS, self._stream(),
+                    nbytes=(4.0 + y.element_size()) * M * d)
 
     def _ln_bwd(self, dy, x, stat, gname, dres, dx_out, M):
         d = self.cfg.d
         lib = hip.load()
         n_slabs = lib.vlg_layernorm_bwd_slabs(M)
         s = self._stream()
-        call("vlg_layernorm_bwd_bf16" if dy.dtype == torch.bfloat16 else "vlg_layernorm_bwd", ptr(dy), ptr(x), ptr(stat[0]), ptr(stat[1]), ptr(self.p(gname)), ptr(dres),
-             ptr(dx_out), ptr(self.slabs), 2 * d, self.slabs.numel(), M, d, s)
+        self._timed("ln_bwd", 0.0, "vlg_layernorm_bwd_bf16" if dy.dtype == torch.bfloat16 else "vlg_layernorm_bwd", ptr(dy), ptr(x), ptr(stat[0]),
+                    ptr(stat[1]), ptr(self.p(gname)), ptr(dres), ptr(dx_out), ptr(self.slabs), 2 * d, self.slabs.numel(), M, d, s,
+                    nbytes=(dy.element_size() + 4.0 + 4.0 + (4.0 if dres is not None else 0.0)) * M * d)
         off = self.layout[gname][0]
         call("vlg_reduce_slabs", ptr(self.slabs), 2 * d, n_slabs, self.grads.data_ptr() + 4 * off, 2 * d, s)
 
@@ -291,15 +293,16 @@ class LayoutEngine:
         B, T, N, M = self._check_batch(batch)
         self._shape = (B, T, N, M)
         s = self._stream()
-        call("vlg_embed_fwd", ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.p("cls_emb")),
-             ptr(self.p("box_w")), ptr(self.p("box_b")), ptr(self.p("time_emb")), ptr(self.x[0]),
-             B, T, N, d, cfg.vocab, s)
+        self._timed("embed_fwd", 0.0, "vlg_embed_fwd", ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.p("cls_emb")),
+                    ptr(self.p("box_w")), ptr(self.p("box_b")), ptr(self.p("time_emb")), ptr(self.x[0]),
+                    B, T, N, d, cfg.vocab, s, nbytes=4.0 * M * d + 24.0 * M)
         for l in range(cfg.n_layers):
             pre = "l%d." % l
             x = self.x[l]
             self._ln_fwd(x, pre + "ln1_g", self.h1[l], self.stats[2 * l], M)
             self._linear(self.h1[l], self.pw(pre + "qkv_w"), self.p(pre + "qkv_b"), self.qkv[l], M, 3 * d, d, EPI_BIAS)
-            call("vlg_attention_fwd" + self._sfx, ptr(self.qkv[l]), ptr(self.att[l]), B * N, T, d, s)
+            self._timed("attn_fwd", 0.0, "vlg_attention_fwd" + self._sfx, ptr(self.qkv[l]), ptr(self.att[l]), B * N, T, d, s,
+                        nbytes=4.0 * self.qkv.element_size() * M * d)
             self._linear(self.att[l], self.pw(pre + "proj_w"), self.p(pre + "proj_b"), self.xmid[l], M, d, d,
                          EPI_BIAS | EPI_RESID, aux_in=x)
             self._ln_fwd(self.xmid[l], pre + "ln2_g", self.h2[l], self.stats[2 * l + 1], M)
@@ -315,9 +318,10 @@ class LayoutEngine:
         L = cfg.n_layers
         self._ln_fwd(self.x[L], "lnf_g", self.xf, self.stats[2 * L], M)
         self._linear(self.xf, self.pw("head_w"), self.p("head_b"), self.out, M, cfg.n_out, d, EPI_BIAS)
-        call("vlg_layout_loss", ptr(self.out), cfg.n_out, ptr(batch["tgt_class"]), ptr(batch["tgt_box"]),
-             ptr(batch["valid"]), ptr(self.dout), ptr(self.loss_out), ptr(self.loss_scratch), B, T, N,
-             cfg.n_classes, SMOOTH_L1_BETA, IOU_EPS, LOSS_W_REG, LOSS_W_STRUCT, LOSS_W_CE, s)
+        self._timed("loss", 0.0, "vlg_layout_loss", ptr(self.out), cfg.n_out, ptr(batch["tgt_class"]), ptr(batch["tgt_box"]),
+                    ptr(batch["valid"]), ptr(self.dout), ptr(self.loss_out), ptr(self.loss_scratch), B, T, N,
+                    cfg.n_classes, SMOOTH_L1_BETA, IOU_EPS, LOSS_W_REG, LOSS_W_STRUCT, LOSS_W_CE, s,
+                    nbytes=(2.0 * 4 * cfg.n_out + 8 + 16 + 4) * M)
         return self.loss_out
 
     # -------------------------------------------------------------------- backward
@@ -393,7 +397,8 @@ class LayoutEngine:
             on_side(("dx",), lambda: self._wgrad(self.dx, self.att[l], pre + "proj_w", M, d, d))
             self._dgrad(self.dx, self.pw(pre + "proj_w"), self.dh, M, d, d)
             before_write("dqkv")
-            call("vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s)
+            self._timed("attn_bwd", 0.0, "vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s,
+                        nbytes=7.0 * self.qkv.element_size() * M * d)
             on_side(("dqkv",), lambda: self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d))
             self._dgrad(self.dqkv, self.pw(pre + "qkv_w"), self.dh, M, 3 * d, d)
             before_write("dx")
@@ -403,8 +408,8 @@ class LayoutEngine:
                 reducer.ready("l%d" % l)
         lib = hip.load()
         emb_len = self.layout["l0.ln1_g"][0]
-        call("vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.slabs),
-             emb_len, self.slabs.numel(), B, T, N, d, cfg.vocab, s)
+        self._timed("embed_bwd", 0.0, "vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.slabs),
+                    emb_len, self.slabs.numel(), B, T, N, d, cfg.vocab, s, nbytes=4.0 * M * d + 24.0 * M)
         call("vlg_reduce_slabs", ptr(self.slabs), emb_len, lib.vlg_embed_bwd_slabs(), ptr(self.grads), emb_len, s)
         join()
         if reducer is not None:
@@ -450,9 +455,9 @@ class LayoutEngine:
                  self.exp_avg_sq.data_ptr() + o, shadow, hi - lo, self.step_count, self.lr,
                  self.beta1, ADAM_BETA2, ADAM_EPS, grad_scale, self._stream())
             return
-        call("vlg_adam_step", self.params.data_ptr() + o, self.grads.data_ptr() + o, self.exp_avg.data_ptr() + o,
-             self.exp_avg_sq.data_ptr() + o, hi - lo, self.step_count, self.lr, self.beta1, ADAM_BETA2, ADAM_EPS,
-             grad_scale, self._stream())
+        self._timed("adam", 0.0, "vlg_adam_step", self.params.data_ptr() + o, self.grads.data_ptr() + o, self.exp_avg.data_ptr() + o,
+                    self.exp_avg_sq.data_ptr() + o, hi - lo, self.step_count, self.lr, self.beta1, ADAM_BETA2, ADAM_EPS,
+                    grad_scale, self._stream(), nbytes=28.0 * (hi - lo))
 
     # ------------------------------------------------------------------- hipGraph
     def use_device_step_counter(self) -> None:
