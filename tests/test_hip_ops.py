@@ -68,6 +68,35 @@ def test_embed_fwd_bwd(H, dev, B, T, N, d):
         o += n
 
 
+def test_embed_class_table_matches_reference_embedding(H, dev):
+    """The class-table term of vlg_embed_fwd / _bwd against the reference's own nn.Embedding(30, dim) lookup and its
+    gradient (reference src/models/simple.py:23,41-42; golden written by oracle/make_golden_embedding.py): box and frame
+    terms switched off (zero weights), reserved id 29 included."""
+    import numpy as np
+    from conftest import GOLDEN
+    z = np.load(GOLDEN + "/embedding_simple.npz")
+    # the kernels take T in {4, 8, 16, 32}: read the 84 stored ids as (B,T,N) = (3,4,7) - a row gather does not care
+    B, T, N = 3, 4, 7
+    ids = torch.from_numpy(z["ids"]).reshape(B, T, N).contiguous().to(dev)
+    vocab, d = z["table"].shape
+    table = torch.from_numpy(z["table"]).to(dev)
+    zeros = torch.zeros(d * 4 + d + T * d, device=dev)
+    box = torch.zeros(B, T, N, 4, device=dev)
+    x = torch.empty(B * N * T, d, device=dev)
+    H.call("vlg_embed_fwd", ids.data_ptr(), box.data_ptr(), table.data_ptr(), zeros.data_ptr(), zeros[d * 4:].data_ptr(),
+           zeros[d * 5:].data_ptr(), x.data_ptr(), B, T, N, d, vocab, stream())
+    got = x.view(B, N, T, d).permute(0, 2, 1, 3).cpu()
+    assert torch.equal(got, torch.from_numpy(z["out"]).reshape(B, T, N, d))  # a row gather: exact
+    dx = torch.from_numpy(z["r"]).reshape(B, T, N, d).permute(0, 2, 1, 3).contiguous().view(B * N * T, d).to(dev)
+    L = vocab * d + d * 4 + d + T * d
+    ns = H.load().vlg_embed_bwd_slabs()
+    slabs = torch.empty(ns * L, device=dev)
+    H.call("vlg_embed_bwd", dx.data_ptr(), ids.data_ptr(), box.data_ptr(), slabs.data_ptr(), L, slabs.numel(), B, T, N, d, vocab,
+           stream())
+    g = reduce_slabs(H, slabs, L, ns, L, dev)
+    assert_close(g[:vocab * d].view(vocab, d), torch.from_numpy(z["dtable"]), rtol=1e-5, atol=1e-6, what="class-table gradient")
+
+
 # ----------------------------------------------------------------------- layer-norm
 @pytest.mark.parametrize("rows,d", [(7, 64), (1000, 256), (513, 512), (64, 128), (40, 1024)])
 def test_layernorm_fwd_bwd(H, dev, rows, d):

@@ -29,7 +29,9 @@ def test_bucketed_variable_n_training(tmp_path, monkeypatch):
         n = batch["slot_class"].shape[2]
         shapes.add(n)
         assert n % 8 == 0 and n <= 32
+        assert batch["slot_class"].is_cuda                # the Trainer's loaders deliver device batches (pinned prefetch)
         dev_batch = {k: v.to(tr.device) for k, v in batch.items()}
+        batch = {k: v.cpu() for k, v in batch.items()}    # the oracle's copy
         loss = tr.engine.forward_backward(dev_batch)
         if checked < 3:                                   # oracle comparison on the first few buckets (initial weights)
             parts, grads = O.loss_and_grads(p, batch, tr.cfg.n_layers)
@@ -49,3 +51,34 @@ def test_bucketed_variable_n_training(tmp_path, monkeypatch):
     tr.train()
     m = tr.validate()
     assert m["loss"] > 0 and m["loss"] == m["loss"]
+
+
+@pytest.mark.parametrize("bucketed", [False, True])
+def test_pinned_prefetch_delivers_the_same_batches(dev, bucketed):
+    """vlg.data.device_prefetch (pinned staging, next batch's H2D on a side stream while the current one is consumed,
+    three rotating slots) must hand over the same bytes in the same order as plain synchronous copies - with a
+    consumer that keeps the device busy on every batch, over more batches than there are slots, and (bucketed) with
+    the batch shape changing between buckets."""
+    from vlg.data import BATCH_KEYS, BucketedClipLoader, ClipLoader, synthetic_clips
+    clips = synthetic_clips(96, T=8, N=16, seed=3, variable_n=bucketed, min_valid=4)
+    cls = BucketedClipLoader if bucketed else ClipLoader
+    kw = dict(batch=4, rank=1, world=2, seed=9, shuffle=True)
+    plain = cls(clips, device=dev, prefetch=False, **kw)
+    fast = cls(clips, device=dev, prefetch=True, **kw)
+    cpu = cls(clips, **kw)
+    for ld in (plain, fast, cpu):
+        ld.set_epoch(2)
+    assert len(plain) == len(fast) == len(cpu) > 5
+    busy = torch.randn(2048, 2048, device=dev)
+    got = []
+    for b in fast:
+        busy = busy @ busy * 1e-3                                   # the consumer's stream is never idle
+        got.append({k: b[k].clone() for k in BATCH_KEYS})           # slots are reused: keep a copy, stream-ordered
+    torch.cuda.synchronize()
+    want = list(plain)
+    ref = list(cpu)
+    assert len(got) == len(want) == len(ref)
+    for g, w, r in zip(got, want, ref):
+        for k in BATCH_KEYS:
+            assert g[k].is_cuda and g[k].is_contiguous() and g[k].shape == w[k].shape
+            assert torch.equal(g[k], w[k]) and torch.equal(g[k].cpu(), r[k]), k

@@ -78,6 +78,16 @@ def main():
         add("gemm wgrad ff2 (gelu on load)", fl(d, ff), "F", lambda: hip.call("vlg_linear_wgrad", P(x_d), d, P(x_ff), ff, P(slabs), d * ff + d, slabs.numel(), M, d, ff, EPI_ACT_GELU, S))
     add("attention fwd", 16.0 * M * d, "B", lambda: hip.call("vlg_attention_fwd", P(x_3d), P(y_d), B * N, T, d, S))
     add("attention bwd", 28.0 * M * d, "B", lambda: hip.call("vlg_attention_bwd", P(x_3d), P(x_d), P(y_3d), B * N, T, d, S))
+    vocab = 21
+    ids = torch.randint(0, vocab, (B, T, N), device=dev)
+    boxes = torch.rand(B, T, N, 4, device=dev)
+    tabs = r(vocab * d + d * 4 + d + T * d)
+    L_emb = vocab * d + d * 4 + d + T * d
+    eslabs = torch.empty(lib.vlg_embed_bwd_slabs() * L_emb, device=dev)
+    add("embed fwd", 4.0 * M * d + 24.0 * M, "B", lambda: hip.call("vlg_embed_fwd", P(ids), P(boxes), P(tabs), tabs.data_ptr() + 4 * vocab * d, tabs.data_ptr() + 4 * (vocab * d + 4 * d),
+                                                                     tabs.data_ptr() + 4 * (vocab * d + 5 * d), P(y_d), B, T, N, d, vocab, S))
+    add("embed bwd", 4.0 * M * d + 24.0 * M, "B", lambda: hip.call("vlg_embed_bwd", P(x_d), P(ids), P(boxes), P(eslabs), L_emb, eslabs.numel(), B, T, N, d, vocab, S))
+    add("embed bwd reduce", 4.0 * L_emb * (lib.vlg_embed_bwd_slabs() + 1), "B", lambda: hip.call("vlg_reduce_slabs", P(eslabs), L_emb, lib.vlg_embed_bwd_slabs(), P(red_dst), L_emb, S))
     add("layernorm fwd", 8.0 * M * d, "B", lambda: hip.call("vlg_layernorm_fwd", P(x_d), P(g), P(g), P(y_d), P(stats[0]), P(stats[1]), M, d, 1e-5, S))
     add("layernorm bwd", 16.0 * M * d, "B", lambda: hip.call("vlg_layernorm_bwd", P(x_d), P(y_d), P(stats[0]), P(stats[1]), P(g), P(x_d), P(y_d), P(slabs), 2 * d, slabs.numel(), M, d, S))
 

@@ -249,6 +249,24 @@ __device__ __forceinline__ void store_tiles16(EL* __restrict__ dst, const f32x4 
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho) st4(dst + 4 * rho, make_float4(o[0][rho], o[1][rho], o[2][rho], o[3][rho]));
 }
+// Same tile, stored through a wave-private LDS tile: the MFMA layout hands a lane 16 channels of one frame in four
+// 16-B pieces 64 B apart, i.e. every direct store instruction writes 64 scattered 16-B pieces; turned through LDS
+// (4 ds_write_b128 + 4 ds_read_b128, conflict-free at the 68-float stride) each store instruction writes four full
+// 256-B rows.  `rows0` = first of the 16 rows (row stride ld elements), column base already applied.
+template <typename EL>
+__device__ __forceinline__ void store_tiles16_rows(float* __restrict__ Tl, EL* __restrict__ rows0, int64_t ld, int lane,
+                                                   const f32x4 (&o)[4]) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) st4(Tl + r * LDT + 16 * g + 4 * rho, make_float4(o[0][rho], o[1][rho], o[2][rho], o[3][rho]));
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = 4 * k + g;
+        st4(rows0 + row * ld + 4 * r, ld4(Tl + row * LDT + 4 * r));
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 // softmax of a TRANSPOSED tile: lane (i, g) holds scores of query i for keys j = 4g + reg
 __device__ __forceinline__ void softmax_t16(f32x4& s, int i, int g, float scale) {
     float mx = -INFINITY;
@@ -296,7 +314,8 @@ __device__ __forceinline__ void attn16_fwd_body(const EL* __restrict__ qkv, EL* 
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     contract_frames16(acc, vk, pt);                           // O^T[c][i] = sum_j V[j][c] P^T[j][i]
-    store_tiles16(o + (seq * 16 + r) * (int64_t)d + hh * HD + 16 * g, acc);
+    __shared__ __attribute__((aligned(16))) float out_tile[4][16 * LDT];
+    store_tiles16_rows(out_tile[threadIdx.x >> 6], o + seq * 16 * (int64_t)d + hh * HD, (int64_t)d, lane, acc);
 }
 __global__ __launch_bounds__(256) void attn16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                          int d, int n_heads, int64_t n_items) {
@@ -321,8 +340,11 @@ __device__ __forceinline__ void attn16_bwd_body(const EL* __restrict__ qkv, cons
     const EL* gbase = dout + seq * 16 * (int64_t)d + hh * HD;
     const float scale = 0.125f;
     f32x4 p, pt, ds, dst_;                                     // plain / transposed probabilities and dS
+    __shared__ __attribute__((aligned(16))) float turn_tile[4][16 * LDT];
+    float* const T = turn_tile[threadIdx.x >> 6];
+    float4 qf[4], kf[4], gf[4];
     {
-        float4 qf[4], kf[4], vf[4], gf[4];
+        float4 vf[4];
         load_rows16(qf, base, ld, r, g);
         load_rows16(kf, base + d, ld, r, g);
         load_rows16(vf, base + 2 * d, ld, r, g);
@@ -346,27 +368,40 @@ __device__ __forceinline__ void attn16_bwd_body(const EL* __restrict__ qkv, cons
             ds[k] = p[k] * (dp[k] - dk) * scale;               // dS[i][j]
         }
     }
-    EL* obase = dqkv + (seq * 16 + r) * ld + hh * HD + 16 * g;
+    EL* obase = dqkv + seq * 16 * ld + hh * HD;
     f32x4 acc[4];
     float4 xk[4];
+    // The three products below contract over the 16 frames, so they need dO, Q, K frame-major ("k-style").  Round 1 fetched
+    // them from HBM a second time in that layout (7 tile loads for 4 tiles; PMC: 1.35x the algorithmic bytes); now the
+    // row-style registers are turned through a 4 KB LDS tile private to the wave: 4 ds_write_b128 + 4 ds_read_b128 per
+    // tile, both conflict-free at the 68-float row stride.  One wave owns the tile and DS operations of a wave execute in
+    // order, so no barrier is needed - only the compiler must not reorder the accesses (wave_barrier).
+    auto turn = [&](const float4 (&rows)[4]) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) st4(T + r * LDT + 16 * f + 4 * g, rows[f]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) xk[rho] = ld4(T + (4 * g + rho) * LDT + 4 * r);
+        __builtin_amdgcn_wave_barrier();
+    };
     // dV[j][c] = sum_i P[i][j] dO[i][c]
-    load_kmajor16(xk, gbase, d, r, g);
+    turn(gf);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     contract_frames16(acc, xk, p);
-    store_tiles16(obase + 2 * d, acc);
+    store_tiles16_rows(T, obase + 2 * d, ld, lane, acc);
     // dK[j][c] = sum_i dS[i][j] Q[i][c]
-    load_kmajor16(xk, base, ld, r, g);
+    turn(qf);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     contract_frames16(acc, xk, ds);
-    store_tiles16(obase + d, acc);
+    store_tiles16_rows(T, obase + d, ld, lane, acc);
     // dQ[i][c] = sum_j dS^T[j][i] K[j][c]
-    load_kmajor16(xk, base + d, ld, r, g);
+    turn(kf);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     contract_frames16(acc, xk, dst_);
-    store_tiles16(obase, acc);
+    store_tiles16_rows(T, obase, ld, lane, acc);
 }
 __global__ __launch_bounds__(256) void attn16_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                          float* __restrict__ dqkv, int d, int n_heads, int64_t n_items) {

@@ -10,9 +10,13 @@
 //
 // One lane owns one token (its C+4 outputs are one 96-B row read with float4 loads), so the
 // class softmax needs no cross-lane traffic; the four loss sums are reduced per wavefront with
-// shuffles, per block through LDS, and leave as one partial per block.  Kernel 1 counts valid
-// slots, kernel 2 does the work, kernel 3 folds the partials into loss_out[4] - three launches,
-// no atomics, reproducible.
+// shuffles, per block through LDS, and leave as one partial per block.  Every block first counts the
+// valid slots ITSELF (the mean's denominator scales every gradient, so it must be known before the
+// first store; M floats = 128 KB from L2, the same exact integer sum in every block - round 1 spent a
+// launch on it), then does its tokens; a second tiny launch folds the partials into loss_out[4].
+// No atomics, reproducible.  (Folding the partials in the LAST block instead would need an agent-scope
+// release in every block and an acquire in the last one, ~3.5 us by MI355X_MICROARCH.md's price list, to
+// save a ~1.5 us boundary and a ~3 us kernel: not taken.)
 #include "common.h"
 
 #define LOSS_BLOCK 256
@@ -23,30 +27,27 @@
 // scratch layout (floats): [0] = 1/max(count,1); [4 .. 4+4*LOSS_MAX_BLOCKS) = per-block partials
 #define LOSS_SCRATCH (4 + 4 * LOSS_MAX_BLOCKS)
 
-// one 1024-thread block, float4 loads: 32 768 slots = 8 loads per thread (a few microseconds; the
-// count must be known before any gradient is written, so it cannot ride in the main kernel)
-__global__ __launch_bounds__(1024) void valid_count_kernel(const float* __restrict__ valid, int64_t n,
-                                                           float* __restrict__ scratch) {
-    __shared__ float red[16];
-    float s = 0.f;
-    const int64_t n4 = n >> 2;
-    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
-        const float4 v = ld4(valid + 4 * i);
-        s += (v.x + v.y) + (v.z + v.w);
-    }
-    for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 1024) s += valid[i];
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) scratch[0] = 1.0f / fmaxf(s, 1.0f);
-}
-
 __global__ __launch_bounds__(LOSS_BLOCK) void layout_loss_kernel(
     const float* __restrict__ out, int ld, const int64_t* __restrict__ tgt_class,
     const float* __restrict__ tgt_box, const float* __restrict__ valid, float* __restrict__ dout,
     float* __restrict__ scratch, int B, int T, int N, float beta, float iou_eps,
     float w_reg, float w_iou, float w_ce) {
     __shared__ float red[LOSS_BLOCK / 64];
-    const float inv_cnt = scratch[0];
+    __shared__ float cnt_sh;
     const int64_t M = (int64_t)B * T * N;
+    {   // 1 / max(#valid, 1): sums of 0/1 flags are exact in fp32 in any order, so every block gets the same value
+        float c = 0.f;
+        const int64_t n4 = M >> 2;
+        for (int64_t i = threadIdx.x; i < n4; i += LOSS_BLOCK) {
+            const float4 v = ld4(valid + 4 * i);
+            c += (v.x + v.y) + (v.z + v.w);
+        }
+        for (int64_t i = 4 * n4 + threadIdx.x; i < M; i += LOSS_BLOCK) c += valid[i];
+        c = block_sum(c, red);
+        if (threadIdx.x == 0) cnt_sh = 1.0f / fmaxf(c, 1.0f);
+        __syncthreads();
+    }
+    const float inv_cnt = cnt_sh;
     float s_reg = 0.f, s_iou = 0.f, s_ce = 0.f;
     for (int64_t m = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; m < M; m += (int64_t)gridDim.x * LOSS_BLOCK) {
         const int t = (int)(m % T);
@@ -164,7 +165,6 @@ extern "C" int vlg_layout_loss(const float* out, int ld, const int64_t* tgt_clas
     int64_t blocks = (M + LOSS_BLOCK - 1) / LOSS_BLOCK;
     if (blocks > LOSS_MAX_BLOCKS) blocks = LOSS_MAX_BLOCKS;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(valid_count_kernel, dim3(1), dim3(1024), 0, s, valid, M, scratch);
     hipLaunchKernelGGL(layout_loss_kernel, dim3((unsigned)blocks), dim3(LOSS_BLOCK), 0, s, out, ld, tgt_class,
                        tgt_box, valid, dout, scratch, B, T, N, beta, iou_eps, w_reg, w_iou, w_ce);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, (int)blocks, loss_out, w_reg,

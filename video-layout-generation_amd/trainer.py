@@ -297,12 +297,15 @@ class Trainer:
         n_train = _knob(args, "train_clips", "VLG_TRAIN_CLIPS", 1024)
         n_val = _knob(args, "val_clips", "VLG_VAL_CLIPS", 256)
         common = dict(batch=self.cfg.B, rank=int(args.rank), world=self.world, seed=seed)
+        if self.device.type == "cuda":       # device batches, pinned staging + one batch ahead on a side stream (vlg/data.py)
+            common["device"] = self.device
         if self.image_mode and self.engine.on_disk:
             # the reference's own data: frame triplets from <train_dir>/{deeplab256_label,leftImg256}/<city>/ (folder.py)
             from vlg.cityscapes import TripletFolder, TripletLoader
             val_dir = getattr(args, "val_dir", None) or args.train_dir
-            self.train_loader = TripletLoader(TripletFolder(args.train_dir), shuffle=True, device=self.device, **common)
-            self.val_loader = TripletLoader(TripletFolder(val_dir), shuffle=False, device=self.device, **common)
+            common["device"] = self.device
+            self.train_loader = TripletLoader(TripletFolder(args.train_dir), shuffle=True, **common)
+            self.val_loader = TripletLoader(TripletFolder(val_dir), shuffle=False, **common)
             args.logger.debug("Finish init trainer")
             return
         if self.image_mode:

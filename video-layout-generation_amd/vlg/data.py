@@ -45,6 +45,56 @@ def to_device(batch: Dict[str, torch.Tensor], device: torch.device, keys=BATCH_K
     return {k: batch[k].to(device, non_blocking=True).contiguous() for k in keys}
 
 
+def device_prefetch(cpu_batches, device: torch.device, keys=BATCH_KEYS) -> Iterator[Dict[str, torch.Tensor]]:
+    """Pinned-memory staging + one-batch-ahead H2D on a side stream (what the reference gets from DataLoader(pin_memory=True)
+    + .cuda(non_blocking=True), src/trainer.py:149-152,184-187): while the step consumes batch i, batch i+1 is gathered
+    into a pinned host buffer and copied to HBM on a second HIP stream; the consumer's stream only waits for that copy's
+    event.  Three rotating slots of pinned + device buffers: a slot is rewritten only after the copy that read its pinned
+    half has finished (host-side event wait) and after the step that used its device half has been enqueued (stream-side
+    event wait).  Yields the SAME bytes in the SAME order as the plain path (tests/test_hip_variable_n.py)."""
+    side = torch.cuda.Stream(device=device)
+    slots = 3
+    bufs: list = [dict() for _ in range(slots)]          # slot -> {shape signature: (pinned dict, device dict)}
+    copied: list = [None] * slots                        # H2D of the slot finished (side stream)
+    done: list = [None] * slots                          # consumer finished with the slot's device buffers (its stream)
+
+    def stage(i: int, b: Dict[str, torch.Tensor]) -> tuple:
+        s = i % slots
+        sig = tuple((k, tuple(b[k].shape), b[k].dtype) for k in keys)
+        if sig not in bufs[s]:
+            bufs[s][sig] = ({k: torch.empty(b[k].shape, dtype=b[k].dtype, pin_memory=True) for k in keys},
+                            {k: torch.empty(b[k].shape, dtype=b[k].dtype, device=device) for k in keys})
+        pinned, dev = bufs[s][sig]
+        if copied[s] is not None:
+            copied[s].synchronize()                      # the previous copy out of this pinned slot is complete
+        for k in keys:
+            pinned[k].copy_(b[k])
+        if done[s] is not None:
+            side.wait_event(done[s])                     # the step that read this device slot has been enqueued and finished
+        with torch.cuda.stream(side):
+            for k in keys:
+                dev[k].copy_(pinned[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        copied[s] = ev
+        return s, dev
+
+    it = iter(cpu_batches)
+    i = 0
+    first = next(it, None)
+    staged = stage(0, first) if first is not None else None
+    while staged is not None:
+        cur, dev = staged
+        nb = next(it, None)
+        i += 1
+        staged = stage(i, nb) if nb is not None else None        # batch i+1's H2D is in flight while batch i is consumed
+        torch.cuda.current_stream(device).wait_event(copied[cur])
+        yield dict(dev)
+        e = torch.cuda.Event()
+        e.record(torch.cuda.current_stream(device))
+        done[cur] = e
+
+
 def shard_indices(n_items: int, rank: int, world: int, epoch: int, seed: int, shuffle: bool = True) -> List[int]:
     """DistributedSampler arithmetic: pad the permutation to a multiple of world by wrapping,
     then rank r takes every world-th index starting at r."""
@@ -62,10 +112,14 @@ class ClipLoader:
     """Fixed-shape loader: every batch is (B, T, N) clips from one synthetic pool."""
 
     def __init__(self, clips: Dict[str, torch.Tensor], batch: int, rank: int = 0, world: int = 1,
-                 seed: int = 1024, shuffle: bool = True, device: Optional[torch.device] = None, keys=BATCH_KEYS):
+                 seed: int = 1024, shuffle: bool = True, device: Optional[torch.device] = None, keys=BATCH_KEYS,
+                 prefetch: bool = True):
+        """device = None: CPU batches.  device = a HIP device: device batches, staged through pinned memory one batch
+        ahead on a side stream (device_prefetch) unless prefetch=False (plain synchronous copies)."""
         self.clips, self.batch, self.rank, self.world = clips, batch, rank, world
         self.seed, self.shuffle, self.device, self.epoch = seed, shuffle, device, 0
         self.keys = tuple(keys)
+        self.prefetch = prefetch
         self.n = clips[self.keys[0]].shape[0]
 
     def set_epoch(self, epoch: int) -> None:
@@ -77,12 +131,21 @@ class ClipLoader:
     def __len__(self) -> int:
         return len(self._indices()) // self.batch          # drop the ragged tail: shapes stay static
 
-    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+    def _cpu_batches(self) -> Iterator[Dict[str, torch.Tensor]]:
         idx = self._indices()
         for i in range(len(self)):
             sel = torch.tensor(idx[i * self.batch:(i + 1) * self.batch])
-            b = {k: self.clips[k][sel] for k in self.keys}
-            yield to_device(b, self.device, self.keys) if self.device is not None else b
+            yield {k: self.clips[k][sel] for k in self.keys}
+
+    def _deliver(self, cpu_batches) -> Iterator[Dict[str, torch.Tensor]]:
+        if self.device is None:
+            return cpu_batches
+        if self.prefetch and self.device.type == "cuda":
+            return device_prefetch(cpu_batches, self.device, self.keys)
+        return (to_device(b, self.device, self.keys) for b in cpu_batches)
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        return iter(self._deliver(self._cpu_batches()))
 
 
 class BucketedClipLoader(ClipLoader):
@@ -115,10 +178,10 @@ class BucketedClipLoader(ClipLoader):
     def __len__(self) -> int:
         return len(self._batches())
 
-    def __iter__(self):
+    def _cpu_batches(self):
         for bn, sel in self._batches():
             b = {}
             for k in BATCH_KEYS:
                 t = self.clips[k][sel]
                 b[k] = t[:, :, :bn].contiguous()
-            yield to_device(b, self.device) if self.device is not None else b
+            yield b
