@@ -99,18 +99,17 @@ def main():
         od, o3, of = bf(y_d), bf(y_3d), bf(y_ff)
         by = lambda *terms: float(sum(terms))
         E = M * d
-        add("fwd qkv  bf16->bf16", by(2 * E, 6 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(w_qkv), d, P(bias), P(o3), 3 * d, 0, 0, M, 3 * d, d, EPI_BIAS | FL | AB | OB, S))
-        add("fwd proj bf16->f32 +resid", by(2 * E, 4 * E, 4 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(w_proj), d, P(bias), P(y_d), d, P(x_d), 0, M, d, d, EPI_BIAS | EPI_RESID | FL | AB, S))
-        add("fwd ff1  bf16->2xbf16 gelu", by(2 * E, 16 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(w_ff1), d, P(bias), P(of), ff, 0, P(hf2), M, ff, d, EPI_BIAS | EPI_GELU | FL | AB | OB, S))
-        add("fwd ff2  bf16->f32 +resid", by(8 * E, 4 * E, 4 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hf), ff, P(w_ff2), ff, P(bias), P(y_d), d, P(x_d), 0, M, d, ff, EPI_BIAS | EPI_RESID | FL | AB, S))
-        wq16, wf16 = bf(w_qkv), bf(w_ff1)
-        add("fwd qkv  bf16->bf16 (bf16 W)", by(2 * E, 6 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(wq16), d, P(bias), P(o3), 3 * d, 0, 0, M, 3 * d, d, EPI_BIAS | FL | AB | BB | OB, S))
-        add("dgrad qkv  bf16->bf16 (bf16 W)", by(6 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(h3), 3 * d, P(wq16), d, P(od), d, 0, M, 3 * d, d, FL | AB | BB | OB, S))
-        add("dgrad ff1  bf16->bf16 (bf16 W)", by(8 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(hf), ff, P(wf16), d, P(od), d, 0, M, ff, d, FL | AB | BB | OB, S))
-        add("dgrad qkv  bf16->bf16", by(6 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(h3), 3 * d, P(w_qkv), d, P(od), d, 0, M, 3 * d, d, FL | AB | OB, S))
-        add("dgrad proj f32->bf16", by(4 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_proj), d, P(od), d, 0, M, d, d, FL | OB, S))
-        add("dgrad ff1  bf16->bf16", by(8 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(hf), ff, P(w_ff1), d, P(od), d, 0, M, ff, d, FL | AB | OB, S))
-        add("dgrad ff2  f32->bf16 dgelu", by(4 * E, 8 * E, 8 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(of), ff, P(hf2), M, d, ff, EPI_DGELU | FL | OB, S))
+        # the storage combinations the bf16 step launches (csrc/gemm_bf16.hip instantiates exactly these): bf16 activations,
+        # the bf16 weight shadow, fp32 residual stream / its gradient
+        wq16, wp16, wf16, wf216 = bf(w_qkv), bf(w_proj), bf(w_ff1), bf(w_ff2)
+        add("fwd qkv  bf16,bf16W->bf16", by(2 * E, 6 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(wq16), d, P(bias), P(o3), 3 * d, 0, 0, M, 3 * d, d, EPI_BIAS | FL | AB | BB | OB, S))
+        add("fwd proj bf16,bf16W->f32 +resid", by(2 * E, 4 * E, 4 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(wp16), d, P(bias), P(y_d), d, P(x_d), 0, M, d, d, EPI_BIAS | EPI_RESID | FL | AB | BB, S))
+        add("fwd ff1  bf16,bf16W->2xbf16 gelu", by(2 * E, 16 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hd), d, P(wf16), d, P(bias), P(of), ff, 0, P(hf2), M, ff, d, EPI_BIAS | EPI_GELU | FL | AB | BB | OB, S))
+        add("fwd ff2  bf16,bf16W->f32 +resid", by(8 * E, 4 * E, 4 * E), "B", lambda: hip.call("vlg_linear_fwd", P(hf), ff, P(wf216), ff, P(bias), P(y_d), d, P(x_d), 0, M, d, ff, EPI_BIAS | EPI_RESID | FL | AB | BB, S))
+        add("dgrad qkv  bf16,bf16W->bf16", by(6 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(h3), 3 * d, P(wq16), d, P(od), d, 0, M, 3 * d, d, FL | AB | BB | OB, S))
+        add("dgrad proj f32,bf16W->bf16", by(4 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(wp16), d, P(od), d, 0, M, d, d, FL | BB | OB, S))
+        add("dgrad ff1  bf16,bf16W->bf16", by(8 * E, 2 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(hf), ff, P(wf16), d, P(od), d, 0, M, ff, d, FL | AB | BB | OB, S))
+        add("dgrad ff2  f32,bf16W->bf16 dgelu", by(4 * E, 8 * E, 8 * E), "B", lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(wf216), ff, P(of), ff, P(hf2), M, d, ff, EPI_DGELU | FL | BB | OB, S))
         for nm, n, k, dy, xx, bits, nb in (("qkv  bf16,bf16", 3 * d, d, h3, hd, AB | BB, by(6 * E, 2 * E)), ("proj f32,bf16", d, d, y_d, hd, BB, by(4 * E, 2 * E)),
                                            ("ff1  bf16,bf16", ff, d, hf, hd, AB | BB, by(8 * E, 2 * E)), ("ff2  f32,bf16", d, ff, x_d, hf, BB, by(4 * E, 8 * E))):
             ns = lib.vlg_linear_wgrad_slabs_for(M, n, k, FL)

@@ -68,7 +68,9 @@ __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
     const float ax = fabsf(x);
     const float e = __expf(-0.5f * x * x);                     // exp(-(x/sqrt2)^2)
-    const float t = __frcp_rn(1.0f + 0.3275911f * 0.70710678118654752f * ax);
+    // v_rcp_f32 (1 ulp) - NOT __frcp_rn, which hipcc expands to the 10-instruction correctly rounded division
+    // (v_div_scale x2, v_rcp, 4 FMAs, v_div_fmas, v_div_fixup): a third of this function, in a GEMM epilogue
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678118654752f * ax);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float tail = 0.5f * poly * e;                        // 1 - Phi(|x|)
     cdf = x >= 0.f ? 1.0f - tail : tail;

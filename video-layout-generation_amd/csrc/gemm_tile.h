@@ -22,11 +22,12 @@ struct GemmArgs {
 
 
 // One operand tile: BR rows (non-contraction) x BK contraction steps.
-template <int BR, bool KC, int BK>
+// NT = threads of the block that stages the tile (256 everywhere but the 8-wave persistent GEMM)
+template <int BR, bool KC, int BK, int NT = GEMM_THREADS>
 struct Tile {
     static constexpr int LDK = BK + 4;                                  // padded row stride of a KC tile
     static constexpr int F4 = BR * BK / 4;                              // float4 per tile
-    static constexpr int NV = (F4 + GEMM_THREADS - 1) / GEMM_THREADS;   // float4 per thread
+    static constexpr int NV = (F4 + NT - 1) / NT;   // float4 per thread
     static constexpr int FLOATS = KC ? BR * LDK : BK * BR;
     static constexpr int PER_ROW = KC ? BK / 4 : BR / 4;                // float4 per memory row
 
@@ -39,8 +40,8 @@ struct Tile {
                                                  int64_t r0, int64_t R, int64_t k0, int64_t kend, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = tid + GEMM_THREADS * i;
-            if (F4 % GEMM_THREADS != 0 && idx >= F4) { r[i] = f4_zero(); continue; }
+            const int idx = tid + NT * i;
+            if (F4 % NT != 0 && idx >= F4) { r[i] = f4_zero(); continue; }
             const int major = idx / PER_ROW, minor = (idx % PER_ROW) << 2;
             // KC: memory row = operand row, column = k.   MC: memory row = k, column = operand row.
             const int64_t grow = KC ? r0 + major : k0 + major;
@@ -58,8 +59,8 @@ struct Tile {
     __device__ static __forceinline__ void sstore(const float4 (&r)[NV], float* S, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = tid + GEMM_THREADS * i;
-            if (F4 % GEMM_THREADS != 0 && idx >= F4) continue;
+            const int idx = tid + NT * i;
+            if (F4 % NT != 0 && idx >= F4) continue;
             if constexpr (KC) st4(S + (idx / PER_ROW) * LDK + ((idx % PER_ROW) << 2), r[i]);
             else st4(S + (idx << 2), r[i]);
         }
