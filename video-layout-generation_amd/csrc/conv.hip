@@ -213,12 +213,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
         TA::sstore(ra, As0 + buf * TA::FLOATS, tid);
         TB::sstore(rb, Bs0 + buf * TB::FLOATS, tid);
     };
-    auto chunk = [&](const float* as, const float* bs, int s) {
-        float a[TM][4], b[TN][4];
+    // Main loop scheduled like gemm.hip's (see there): fragment reads double-buffered in registers (chunk s+1's LDS reads
+    // are issued before chunk s's MFMAs), the steady-state iteration one basic block with the staging instructions pinned
+    // between the MFMAs of chunk SS, the iteration's one barrier in front of the LAST chunk's MFMAs with the next tile's
+    // first fragments read behind it.
+    auto ldfrag = [&](float (&a)[TM][4], float (&b)[TN][4], const float* as, const float* bs, int s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) TA::frag(a[i], as, (wm * TM + i) * 32 + l31, s, h);
 #pragma unroll
         for (int j = 0; j < TN; ++j) TB::frag(b[j], bs, (wn * TN + j) * 32 + l31, s, h);
+    };
+    auto mma = [&](const float (&a)[TM][4], const float (&b)[TN][4]) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -227,29 +232,63 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
     };
-
+    static_assert(NCH >= 2 && NCH % 2 == 0, "fragment sets alternate by chunk parity");
+    constexpr int SS = NCH / 2 - 1;
+    float fa[2][TM][4], fb[2][TN][4];
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
-    if (nk > 0) { gload(kbeg); sstore(0); }
-    if (nk > 1) gload(kbeg + BK);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    auto iter = [&](int kt, auto store_tag, auto load_tag, auto next_tag) {
+        constexpr bool STORE = decltype(store_tag)::value, LOAD = decltype(load_tag)::value, NEXT = decltype(next_tag)::value;
         const int cur = kt & 1;
         const float* as = As0 + cur * TA::FLOATS;
         const float* bs = Bs0 + cur * TB::FLOATS;
 #pragma unroll
-        for (int c = 0; c < NCH / 2; ++c) chunk(as, bs, c);
-        if (kt + 1 < nk) sstore(cur ^ 1);
-        if (kt + 2 < nk) gload(kbeg + (int64_t)(kt + 2) * BK);
+        for (int s = 0; s < NCH; ++s) {
+            if (s + 1 < NCH) ldfrag(fa[(s + 1) & 1], fb[(s + 1) & 1], as, bs, s + 1);
+            if (s == NCH - 1) {
+                if constexpr (MODE == CONV_WGRAD) {
+                    if (tn == 0 && tid < BM) {                  // bias gradient: column sums of the dOut tile (before the barrier
+#pragma unroll 8                                               // frees this buffer for the next iteration's staging)
+                        for (int kk = 0; kk < BK; ++kk) colacc += as[kk * BM + tid];
+                    }
+                }
+                if constexpr (NEXT) {
+                    __syncthreads();
+                    ldfrag(fa[0], fb[0], As0 + (cur ^ 1) * TA::FLOATS, Bs0 + (cur ^ 1) * TB::FLOATS, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == SS) {
+                if constexpr (STORE) sstore(cur ^ 1);
+                if constexpr (LOAD) gload(kbeg + (int64_t)(kt + 2) * BK);
+            }
+            mma(fa[s & 1], fb[s & 1]);
+            if (s == SS && (STORE || LOAD)) {
+                constexpr int N_MFMA = 4 * TM * TN, N_ST = (STORE ? TA::NV + TB::NV : 0), N_LD = (LOAD ? TA::NV + TB::NV : 0);
+                constexpr int PER = (N_ST + N_LD + N_MFMA - 1) / N_MFMA;
 #pragma unroll
-        for (int c = NCH / 2; c < NCH; ++c) chunk(as, bs, c);
-        if constexpr (MODE == CONV_WGRAD) {
-            if (tn == 0 && tid < BM) {                          // bias gradient: column sums of the dOut tile
-#pragma unroll 8
-                for (int kk = 0; kk < BK; ++kk) colacc += as[kk * BM + tid];
+                for (int i = 0; i < N_MFMA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int slot = i * PER + q;
+                        if (slot < N_ST) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        else if (slot < N_ST + N_LD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
             }
         }
-        __syncthreads();
+    };
+    if (nk > 0) { gload(kbeg); sstore(0); }
+    if (nk > 1) gload(kbeg + BK);
+    __syncthreads();
+    if (nk > 0) ldfrag(fa[0], fb[0], As0, Bs0, 0);
+    {
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) iter(kt, std::true_type{}, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { iter(kt, std::true_type{}, std::false_type{}, std::true_type{}); ++kt; }
+        if (kt < nk) iter(kt, std::false_type{}, std::false_type{}, std::false_type{});
     }
+    __syncthreads();
 
     // ---- epilogue (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h)
     float* Cs = g.C + (int64_t)split * g.slab_stride;
