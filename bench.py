@@ -110,6 +110,21 @@ def cpu_baseline(cfg, steps: int = 3):
                       % (n, cfg.B, cfg.T, cfg.N, cfg.d, cfg.n_layers, el)}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on fd 1 when its first communicator comes up; the contract is ONE JSON line on
+    stdout, so the communicator is brought up with fd 1 pointing at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def timed_steps(step_fn, n: int) -> float:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -148,7 +163,8 @@ def main():
     if os.environ.get("VLG_BENCH_ONE_DEVICE", "0") == "1":
         # rehearsal with N processes on ONE device: each HIP process opens 4 hardware queues by default (+ gloo's copy
         # streams); beyond the device's hardware queue slots the driver time-slices the run list and a 6 ms step takes 69 s
-        # (measured at 4 ranks: 69 235 ms / step with the default, 36 ms with 2 queues per process - DESIGN.md (e)).
+        # (measured at 4 ranks: 69 235 ms / step with the default, 36 ms with 2 queues per process - DESIGN.md (e),
+        # profiles/r02_dp4_*.log).
         # Read by the HIP runtime when it starts, so it is set before the first HIP call.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     if not torch.cuda.is_available():
@@ -162,10 +178,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         backend = os.environ.get("VLG_BENCH_BACKEND", "nccl")                       # nccl == RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=dev)
-        else:                                        # rehearsal of the multi-rank control flow on one GPU (RCCL refuses that)
-            dist.init_process_group(backend=backend, world_size=world, rank=rank)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=dev)
+            else:                                    # rehearsal of the multi-rank control flow on one GPU (RCCL refuses that)
+                dist.init_process_group(backend=backend, world_size=world, rank=rank)
+            # communicator set-up (RCCL builds its rings on the first collective) is not part of a step: do it now
+            dist.all_reduce(torch.zeros(4, device=dev))
+            torch.cuda.synchronize()
 
     from vlg.data import synthetic_clips, to_device
     from vlg.dp import GradReducer, bucket_ranges
@@ -189,10 +209,6 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if reducer is not None:
-        # communicator set-up (RCCL builds its rings on the first collective) is not part of a step: do it now
-        dist.all_reduce(torch.zeros(4, device=dev))
-        torch.cuda.synchronize()
     step_fn = lambda: eng.train_step(batch, reducer)
     if args.graph:
         if reducer is not None:
