@@ -40,7 +40,7 @@ extern "C" {
 int         vlg_abi_version(void);
 const char* vlg_build_arch(void);          /* "gfx950" */
 
-/* diagnostic only (tools/clock_probe.py): when set to a device buffer of 2*blocks uint64, every block of the next
+/* diagnostic only (tools/diag/gemm_shader_clock.py): when set to a device buffer of 2*blocks uint64, every block of the next
  * GEMM launches records {shader-clock ticks, 100 MHz ticks} of its main loop; NULL switches it off */
 void vlg_debug_set_clock_probe(unsigned long long* buf);
 

@@ -11,7 +11,8 @@ dev = torch.device("cuda:0")
 cfg = LayoutConfig(B=32, T=16, N=64, d=256, n_layers=4)
 eng = LayoutEngine(cfg, dev, seed=SEED)
 batch = to_device(synthetic_clips(cfg.B, cfg.T, cfg.N, seed=SEED), dev)
-variants = {"serial": dict(overlap_wgrad=False), "overlap": dict(overlap_wgrad=True)}
+variants = {"serial": dict(overlap_wgrad=False, overlap_small=False), "overlap_wgrad": dict(overlap_wgrad=True, overlap_small=False),
+            "overlap_small": dict(overlap_wgrad=False, overlap_small=True)}
 if len(sys.argv) > 1 and sys.argv[1] == "gelu":
     variants = {"store_gl": dict(gelu_on_load=False), "gelu_on_load": dict(gelu_on_load=True)}
 res = {k: [] for k in variants}

@@ -2,7 +2,7 @@
 """Diagnostic: is the fp32 GEMM's clock data-dependent?  Same launch (ff2 forward shape) on random-normal, all-zero and
 constant operands: in-kernel clock (s_memtime / s_memrealtime) and achieved TFLOP/s after 1.5 s of back-to-back launches."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "video-layout-generation_amd")]
 import torch
 from vlg import hip

@@ -2,7 +2,7 @@
 """Diagnostic: main-loop ticks of each fp32 GEMM shape of the step (clock probe in gemm_f32_kernel) next to its MFMA
 cycles: separates loop efficiency from prologue / epilogue / launch overhead."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "video-layout-generation_amd")]
 import torch
 from vlg import hip

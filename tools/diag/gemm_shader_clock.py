@@ -2,7 +2,7 @@
 """Diagnostic: in-kernel shader clock of the fp32 GEMM main loop (guide 'DVFS give-back' item 6):
 clock = d(s_memtime) / d(s_memrealtime) * 100 MHz, median over blocks, after 2 s of back-to-back launches."""
 import ctypes, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "video-layout-generation_amd")]
 import torch
 from vlg import hip

@@ -2,7 +2,7 @@
 """Diagnostic: which blocks of the fp32 weight-gradient GEMM are slow?  Per-block main-loop time grouped by XCD
 (blockIdx & 7), by K split and by output tile."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "video-layout-generation_amd")]
 import torch
 from vlg import hip

@@ -204,6 +204,9 @@ class LayoutEngine:
         # a kernel's own duration no longer says anything about that kernel (bench.py's per-kernel roofline).
         self.side = torch.cuda.Stream(device=self.device)
         self.overlap_wgrad = os.environ.get("VLG_OVERLAP_WGRAD", "0") == "1"
+        # second option: the bandwidth-bound kernels of backward (layer-norm backward, attention backward) run on the side
+        # stream BESIDE the weight-gradient GEMM that does not depend on them (see backward)
+        self.overlap_small = os.environ.get("VLG_OVERLAP_SMALL", "0") == "1"
 
     # --------------------------------------------------------------------- helpers
     @staticmethod
@@ -380,6 +383,10 @@ class LayoutEngine:
         if reducer is not None:
             join()
             reducer.ready("head")
+        if self.overlap_small and not self.overlap_wgrad:
+            self._backward_layers_paired(B, T, N, M, reducer)
+            self._backward_tail(batch, B, T, N, M, reducer)
+            return
         for l in reversed(range(L)):
             pre = "l%d." % l
             # FFN:  x_out = xmid + W2 gelu(W1 h2 + b1) + b2
@@ -406,14 +413,57 @@ class LayoutEngine:
             if reducer is not None:
                 join()
                 reducer.ready("l%d" % l)
+        join()
+        self._backward_tail(batch, B, T, N, M, reducer)
+
+    def _backward_tail(self, batch, B, T, N, M, reducer) -> None:
+        cfg, d = self.cfg, self.cfg.d
         lib = hip.load()
+        s = self._stream()
         emb_len = self.layout["l0.ln1_g"][0]
         self._timed("embed_bwd", 0.0, "vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.slabs),
                     emb_len, self.slabs.numel(), B, T, N, d, cfg.vocab, s, nbytes=4.0 * M * d + 24.0 * M)
         call("vlg_reduce_slabs", ptr(self.slabs), emb_len, lib.vlg_embed_bwd_slabs(), ptr(self.grads), emb_len, s)
-        join()
         if reducer is not None:
             reducer.ready("embed")
+
+    def _backward_layers_paired(self, B, T, N, M, reducer) -> None:
+        """Backward of the layers with every bandwidth-bound kernel of the chain launched on the side stream BESIDE the
+        weight-gradient GEMM that does not depend on it: layer-norm-2 backward beside the FFN1 weight gradient, attention
+        backward beside the output-projection weight gradient, layer-norm-1 backward beside the QKV weight gradient.  The
+        GEMM is bound by the matrix pipes and leaves most of the HBM bandwidth idle; its partner needs no LDS and few
+        registers, so its blocks fit next to the GEMM's on every CU.  Each pair is fork -> two launches -> join."""
+        cfg, d, ff = self.cfg, self.cfg.d, self.cfg.d_ff
+        main = torch.cuda.current_stream(self.device)
+        side = self.side
+
+        def beside(side_fn, main_fn):
+            e = torch.cuda.Event()
+            e.record(main)
+            side.wait_event(e)
+            with torch.cuda.stream(side):
+                side_fn()
+                done = torch.cuda.Event()
+                done.record(side)
+            main_fn()
+            main.wait_event(done)
+
+        for l in reversed(range(cfg.n_layers)):
+            pre = "l%d." % l
+            self._wgrad(self.dx, self.gl[l], pre + "ff2_w", M, d, ff)
+            self._dgrad(self.dx, self.pw(pre + "ff2_w"), self.du, M, d, ff, EPI_DGELU, aux_in=self.u[l])
+            self._dgrad(self.du, self.pw(pre + "ff1_w"), self.dh, M, ff, d)
+            beside(lambda: self._ln_bwd(self.dh, self.xmid[l], self.stats[2 * l + 1], pre + "ln2_g", self.dx, self.dx, M),
+                   lambda: self._wgrad(self.du, self.h2[l], pre + "ff1_w", M, ff, d))
+            self._dgrad(self.dx, self.pw(pre + "proj_w"), self.dh, M, d, d)
+            beside(lambda: self._timed("attn_bwd", 0.0, "vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv),
+                                       B * N, T, d, self._stream(), nbytes=7.0 * self.qkv.element_size() * M * d),
+                   lambda: self._wgrad(self.dx, self.att[l], pre + "proj_w", M, d, d))
+            self._dgrad(self.dqkv, self.pw(pre + "qkv_w"), self.dh, M, 3 * d, d)
+            beside(lambda: self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M),
+                   lambda: self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d))
+            if reducer is not None:
+                reducer.ready("l%d" % l)
 
     def forward_backward(self, batch: Dict[str, torch.Tensor], reducer=None) -> torch.Tensor:
         loss = self.forward(batch)
