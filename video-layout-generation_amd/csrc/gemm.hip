@@ -82,6 +82,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave - wm * WN;
+#ifdef VLG_TIMELINE
+    // diagnostic build only (tools/diag/gemm_timeline.py): 100 MHz stamps at entry / loop start / loop end / exit + placement
+    const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tl_loop0 = 0, tl_loop1 = 0;
+#endif
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -112,10 +117,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
         }
     }
 
+#ifndef VLG_TIMELINE
     unsigned long long t0 = 0, r0 = 0;
     if (g.clock_probe) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     float4 ra[TA::NV], rb[TB::NV];
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
+#ifdef VLG_PRIO_MAIN
+    __builtin_amdgcn_s_setprio(VLG_PRIO_MAIN);
+#endif
     auto act = [&](float4 (&xa)[TA::NV], float4 (&xb)[TB::NV]) {
         if constexpr ((EPI & GEMM_A_GELU) != 0) {
 #pragma unroll
@@ -224,13 +234,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     };
     // interior blocks (every tile fully inside both operands) take the unguarded instantiation
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) % BK) == 0);
+#ifdef VLG_TIMELINE
+    tl_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (interior) mainloop(std::false_type{});
     else mainloop(std::true_type{});
+#ifdef VLG_TIMELINE
+    tl_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
+#ifndef VLG_TIMELINE
     if (g.clock_probe && tid == 0) {
         g.clock_probe[2 * bid] = __builtin_amdgcn_s_memtime() - t0;
         g.clock_probe[2 * bid + 1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
+#endif
+#ifdef VLG_PRIO_MAIN
+    __builtin_amdgcn_s_setprio(VLG_PRIO_EPI);
+#endif
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h.
     // 32 lanes of a half write one 128-B row segment per store.
     EO* Cs = static_cast<EO*>(g.C) + (int64_t)split * g.slab_stride;
@@ -268,6 +289,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     };
     if (full) emit(std::false_type{});
     else emit(std::true_type{});
+#ifdef VLG_TIMELINE
+    if (g.clock_probe) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tl_exit = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* o = g.clock_probe + 8 * (size_t)bid;
+            o[0] = tl_entry; o[1] = tl_loop0; o[2] = tl_loop1; o[3] = tl_exit;
+            o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));        // HW_REG_HW_ID
+            o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));       // HW_REG_XCC_ID
+            o[6] = (unsigned long long)tile; o[7] = (unsigned long long)split;
+        }
+    }
+#endif
     if constexpr (COLSUM) {
         static_assert(!A_KC, "column sums are taken from a contraction-major A tile");
         if (tn == 0) {                                  // block-uniform; the tiles are dead (the main loop ended on a barrier)
