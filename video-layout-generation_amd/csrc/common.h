@@ -87,6 +87,95 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return c + x * p;
 }
 
+// Two elements at a time, on packed fp32 instructions (v_pk_mul / v_pk_fma / v_pk_add_f32: one issue slot for two lanes'
+// worth of work).  For the fp32 GEMM epilogues: v_mfma_f32_32x32x2_f32 and the vector ALU of a SIMD execute SERIALLY
+// (tools/micro/mfma_f32_valu_share.hip: +8 cycles of matrix time per vector instruction of ANY wave on the SIMD, +12
+// per transcendental, packed or not), so an epilogue's vector instruction count is paid in matrix throughput.
+// Same formulas as gelu_parts above; branch-free:  gelu(x) = max(x, 0) - |x * tail|,  Phi(x) = 0.5 + copysign(0.5 - tail, x).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v2f v2(float a) { return v2f{a, a}; }
+// N pairs in LOCKSTEP: every step is a burst of N independent instructions.  A wave in its epilogue shares the SIMD with
+// waves that issue 64-cycle MFMAs; a lone ready vector instruction waits for the MFMA in flight, so a dependent chain
+// advances one link per MFMA (a 17-link chain per pair = ~17 us per 64x64 tile), while N independent instructions issue
+// back to back behind ONE wait.  The steps are fenced so the scheduler keeps them whole.
+#define VLG_STEP() __builtin_amdgcn_sched_barrier(0)
+template <int N>
+__device__ __forceinline__ void gelu_parts2n(const v2f (&x)[N], v2f (&tail)[N], v2f (&e)[N]) {
+    const float k = 0.3275911f * 0.70710678118654752f;
+    v2f t[N], p[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) e[n] = x[n] * x[n];
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) e[n] = e[n] * v2(-0.5f * 1.4426950408889634f);
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) t[n] = v2f{fmaf(fabsf(x[n].x), k, 1.0f), fmaf(fabsf(x[n].y), k, 1.0f)};
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) e[n] = v2f{__builtin_amdgcn_exp2f(e[n].x), __builtin_amdgcn_exp2f(e[n].y)};      // exp(-x^2 / 2)
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) t[n] = v2f{__builtin_amdgcn_rcpf(t[n].x), __builtin_amdgcn_rcpf(t[n].y)};
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(t[n], v2(0.5f * 1.061405429f), v2(0.5f * -1.453152027f));
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(t[n], p[n], v2(0.5f * 1.421413741f));
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(t[n], p[n], v2(0.5f * -0.284496736f));
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(t[n], p[n], v2(0.5f * 0.254829592f));
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) p[n] = p[n] * t[n];
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) tail[n] = p[n] * e[n];                                                            // 1 - Phi(|x|)
+    VLG_STEP();
+}
+// v_max_f32 against 0 in ONE instruction (fmaxf() adds a canonicalising v_max_f32 x, x, x in front)
+__device__ __forceinline__ float relu_f(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void gelu2n(v2f (&x)[N]) {            // in place
+    v2f tail[N], e[N];
+    gelu_parts2n<N>(x, tail, e);
+#pragma unroll
+    for (int n = 0; n < N; ++n) tail[n] = x[n] * tail[n];
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) x[n] = v2f{relu_f(x[n].x), relu_f(x[n].y)};
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) x[n] = v2f{x[n].x - fabsf(tail[n].x), x[n].y - fabsf(tail[n].y)};
+    VLG_STEP();
+}
+template <int N>
+__device__ __forceinline__ void dgelu2n(const v2f (&x)[N], v2f (&d)[N]) {
+    v2f tail[N], e[N];
+    gelu_parts2n<N>(x, tail, e);
+#pragma unroll
+    for (int n = 0; n < N; ++n) tail[n] = v2(0.5f) - tail[n];                                                     // >= 0
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) tail[n] = v2f{__builtin_copysignf(tail[n].x, x[n].x), __builtin_copysignf(tail[n].y, x[n].y)};
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) { tail[n] = tail[n] + v2(0.5f); e[n] = x[n] * e[n]; }
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) d[n] = __builtin_elementwise_fma(e[n], v2(0.39894228040143268f), tail[n]);
+    VLG_STEP();
+}
+
 // block-wide sum of one float per thread; result valid in thread 0 (smem >= blockDim/64 floats)
 __device__ __forceinline__ float block_sum(float v, float* smem) {
     v = wave_sum(v);

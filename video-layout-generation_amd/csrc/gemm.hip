@@ -41,6 +41,12 @@
 #define GEMM_B_GELU (1 << 21)
 __device__ __forceinline__ float4 gelu4(float4 v) { return make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w)); }
 
+// raw buffer descriptor over [p, p + 2 GB): base in the descriptor, offsets in a VGPR (per thread) and an SGPR (per wave)
+// (loads beyond `bytes` return zeros, stores beyond it are dropped)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vlg_rsrc(const void* p, int bytes = 0x7fffffff) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
 #ifdef VLG_NO_SCHED_FENCE
 #define VLG_SCHED_FENCE()
 #else
@@ -48,7 +54,14 @@ __device__ __forceinline__ float4 gelu4(float4 v) { return make_float4(gelu_f(v.
 #endif
 
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(const GemmArgs g) {
+    // A new block's waves share their SIMDs with an OLDER block that issues MFMAs back to back, and the vector ALU serves
+    // the oldest wave first: at equal priority the newcomer's index arithmetic - and with it its first tile loads - is
+    // starved until the older block leaves its main loop (per-CU timelines: a block's first stamp coincides with its
+    // neighbour's loop end), and every block then waits out its first loads with the matrix pipe idle.  So the prologue
+    // runs at raised priority (its ~130 vector instructions slip in between the neighbour's MFMAs) and drops back in
+    // front of its own main loop.
+    __builtin_amdgcn_s_setprio(3);
     using EO = float;
     const float* const gA = static_cast<const float*>(g.A);
     const float* const gB = static_cast<const float*>(g.B);
@@ -89,32 +102,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
 #endif
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // bias gradient (COLSUM): every thread sums the four dY rows 4*(tid % PER_ROW) .. +3 of the tiles it stages, straight
     // from its staging registers (no LDS reads, no serial chain on two of the four waves); combined through LDS at the end
-    float4 colacc = f4_zero();
-    const float cs_on = (COLSUM && tn == 0) ? 1.f : 0.f;
+    // (two packed adds per float4, in every block: a block-uniform branch around them would cut the hand-scheduled
+    // iteration into several basic blocks; only the tn == 0 blocks write their sums out)
+    v2f col_lo = v2(0.f), col_hi = v2(0.f);
     auto colsum = [&](const float4 (&xa)[TA::NV]) {
 #pragma unroll
         for (int i = 0; i < TA::NV; ++i) {
-            colacc.x = fmaf(cs_on, xa[i].x, colacc.x); colacc.y = fmaf(cs_on, xa[i].y, colacc.y);
-            colacc.z = fmaf(cs_on, xa[i].z, colacc.z); colacc.w = fmaf(cs_on, xa[i].w, colacc.w);
+            col_lo += v2f{xa[i].x, xa[i].y};
+            col_hi += v2f{xa[i].z, xa[i].w};
         }
     };
-    // bias is fetched before the main loop so no load is pending in the store epilogue
-    float bv[TN];
+    // the accumulators START from the bias (a lane's 16 accumulators of a 32x32 tile share one column): no vector
+    // instruction is spent on it in the epilogue, where every one of them costs matrix time (see common.h, gelu2)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        bv[j] = 0.f;
+        float bvj = 0.f;
         if constexpr ((EPI & VLG_EPI_BIAS) != 0) {
             const int col = n0 + (wn * TN + j) * 32 + l31;
-            bv[j] = g.bias[col < g.N ? col : g.N - 1];
+            bvj = g.bias[col < g.N ? col : g.N - 1];
         }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bvj;
     }
 
 #ifndef VLG_TIMELINE
@@ -123,9 +135,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
 #endif
     float4 ra[TA::NV], rb[TB::NV];
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
-#ifdef VLG_PRIO_MAIN
-    __builtin_amdgcn_s_setprio(VLG_PRIO_MAIN);
-#endif
+    bool fast_tile = false;
     auto act = [&](float4 (&xa)[TA::NV], float4 (&xb)[TB::NV]) {
         if constexpr ((EPI & GEMM_A_GELU) != 0) {
 #pragma unroll
@@ -226,19 +236,134 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
         if (nk > 1) load(ra, rb, 1);
         __syncthreads();
         if (nk > 0) ldfrag(fa[0], fb[0], As0, Bs0, 0);
+        __builtin_amdgcn_s_setprio(0);
         int kt = 0;
         for (; kt + 2 < nk; ++kt) iter(kt, ra, rb, std::true_type{}, std::true_type{}, std::true_type{});
         if (kt + 1 < nk) { iter(kt, ra, rb, std::true_type{}, std::false_type{}, std::true_type{}); ++kt; }
         if (kt < nk) iter(kt, ra, rb, std::false_type{}, std::false_type{}, std::false_type{});
         __syncthreads();                           // the tiles are dead from here on (the COLSUM epilogue reuses the LDS)
     };
+    // ---- fast path (round 2, second half): NO vector-ALU instruction in the steady-state iteration.
+    // v_mfma_f32_32x32x2_f32 and the vector ALU of a SIMD execute serially (tools/micro/mfma_f32_valu_share.hip: every
+    // vector instruction of any wave on the SIMD costs 8 cycles of matrix time), and the loop above spent ~26 of them per
+    // iteration on addresses (64-bit global pointers, LDS addresses that depend on the buffer parity): 6-8 % of the
+    // matrix pipe.  Here the global loads are buffer loads - one loop-constant byte offset per thread and operand, the K
+    // advance and the float4 number in the SCALAR offset - and two iterations are unrolled so the LDS buffer is a compile-
+    // time constant and every LDS address is one loop-constant register plus an instruction immediate.
+    constexpr bool FAST = BM == 128 && BN == 128 && (EPI & (GEMM_A_GELU | GEMM_B_GELU)) == 0;
+    auto mainloop_fast = [&]() __attribute__((always_inline)) {
+        const float* pa = A_KC ? gA + m0 * g.lda + kbeg : gA + kbeg * g.lda + m0;
+        const float* pb = B_KC ? gB + (int64_t)n0 * g.ldb + kbeg : gB + kbeg * g.ldb + n0;
+        // a contraction-major operand's descriptor ends with the K range of this block: the loads the last two iterations
+        // issue beyond it return zeros (exact no-ops in the bias-gradient sums); a K-contiguous operand re-reads its last
+        // K tile instead (clamped tile index)
+        const int ext_b = (int)(kend - kbeg);
+        const __amdgpu_buffer_rsrc_t da = A_KC ? vlg_rsrc(pa) : vlg_rsrc(pa, ext_b * g.lda * 4);
+        const __amdgpu_buffer_rsrc_t db = B_KC ? vlg_rsrc(pb) : vlg_rsrc(pb, ext_b * g.ldb * 4);
+        const __amdgpu_buffer_rsrc_t dza = vlg_rsrc(pa, 0), dzb = vlg_rsrc(pb, 0);      // empty: every load returns zeros
+        const int va = TA::voff_bytes(g.lda, tid), vb = TB::voff_bytes(g.ldb, tid);
+        const int a_is = TA::ISTEP * g.lda * 4, b_is = TB::ISTEP * g.ldb * 4;              // bytes between a thread's float4
+        const int a_ks = A_KC ? BK * 4 : BK * g.lda * 4, b_ks = B_KC ? BK * 4 : BK * g.ldb * 4;   // bytes per K tile
+        float* const aw = smem + TA::soff(tid);
+        float* const bw = smem + 2 * TA::FLOATS + TB::soff(tid);
+        const float* const ar = smem + TA::roff(wm * TM * 32 + l31, h);
+        const float* const br = smem + 2 * TA::FLOATS + TB::roff(wn * TN * 32 + l31, h);
+        v4f xa[TA::NV], xb[TB::NV];
+        auto load = [&](int t) __attribute__((always_inline)) {
+            // K tiles past the end read as zeros: through the empty descriptor (K-contiguous operand) or past the end of
+            // the operand's own descriptor (contraction-major operand)
+            const bool in = t < nk;
+            const __amdgpu_buffer_rsrc_t ua = (A_KC && !in) ? dza : da, ub = (B_KC && !in) ? dzb : db;
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) xa[i] = __builtin_amdgcn_raw_buffer_load_b128(ua, va, t * a_ks + i * a_is, 0);
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) xb[i] = __builtin_amdgcn_raw_buffer_load_b128(ub, vb, t * b_ks + i * b_is, 0);
+        };
+        auto store = [&](int c) __attribute__((always_inline)) {
+            if constexpr (COLSUM) {
+#pragma unroll
+                for (int i = 0; i < TA::NV; ++i) {
+                    // (as asm: hipcc merges the two halves into one 4-wide add and then splits THAT into four v_add_f32)
+                    const v2f lo = __builtin_shufflevector(xa[i], xa[i], 0, 1), hi = __builtin_shufflevector(xa[i], xa[i], 2, 3);
+                    asm("v_pk_add_f32 %0, %0, %1" : "+v"(col_lo) : "v"(lo));
+                    asm("v_pk_add_f32 %0, %0, %1" : "+v"(col_hi) : "v"(hi));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) *reinterpret_cast<v4f*>(aw + c * TA::FLOATS + i * TA::SSTEP) = xa[i];
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) *reinterpret_cast<v4f*>(bw + c * TB::FLOATS + i * TB::SSTEP) = xb[i];
+        };
+        auto ldf = [&](float (&a)[TM][4], float (&b)[TN][4], int c, int s) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) TA::frag_at(a[i], ar + c * TA::FLOATS, i, s);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) TB::frag_at(b[j], br + c * TB::FLOATS, j, s);
+        };
+        constexpr int SS = NCH / 2 - 1;
+        float fa[2][TM][4], fb[2][TN][4];
+        // cur is a literal at every call site (the lambda is always inlined), so cur * FLOATS folds into the immediates.
+        // There are NO peeled tail iterations: the last two iterations run the same code - their loads return zeros, their
+        // LDS writes go to the buffer nobody reads any more and the fragments read behind the last barrier are dropped.  One copy of the iteration per buffer parity keeps the code small and the
+        // register allocation tight (seven inlined tail copies cost 60+ registers and spills).
+        auto iter = [&](int kt, int cur) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < NCH; ++s) {
+                if (s + 1 < NCH) ldf(fa[(s + 1) & 1], fb[(s + 1) & 1], cur, s + 1);
+                if (s == NCH - 1) {
+                    __syncthreads();
+                    ldf(fa[0], fb[0], cur ^ 1, 0);
+                }
+                VLG_SCHED_FENCE();
+                if (s == SS) {
+                    store(cur ^ 1);
+                    load(kt + 2);
+                }
+                mma(fa[s & 1], fb[s & 1]);
+                if (s == SS) {
+                    constexpr int N_MFMA = 4 * TM * TN, N_ST = TA::NV + TB::NV, N_LD = TA::NV + TB::NV;
+                    constexpr int PER = (N_ST + N_LD + N_MFMA - 1) / N_MFMA;
+#pragma unroll
+                    for (int i = 0; i < N_MFMA; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                        for (int q = 0; q < PER; ++q) {
+                            const int slot = i * PER + q;
+                            if (slot < N_ST) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                            else if (slot < N_ST + N_LD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
+                    }
+                }
+            }
+        };
+        // (an odd nk runs one iteration on a zero tile)
+        load(0);
+        store(0);
+        load(1);
+        __syncthreads();
+        ldf(fa[0], fb[0], 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        for (int kt = 0; kt < nk; kt += 2) { iter(kt, 0); iter(kt + 1, 1); }
+        __syncthreads();
+    };
     // interior blocks (every tile fully inside both operands) take the unguarded instantiation
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) % BK) == 0);
 #ifdef VLG_TIMELINE
     tl_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (interior) mainloop(std::false_type{});
-    else mainloop(std::true_type{});
+    if constexpr (FAST) {
+        // byte offsets from the tile origins are 32-bit in the fast path
+        const int64_t ext = kend - kbeg;
+        const int64_t span_a = A_KC ? (int64_t)(BM - 1) * g.lda + ext : ext * g.lda + BM;
+        const int64_t span_b = B_KC ? (int64_t)(BN - 1) * g.ldb + ext : ext * g.ldb + BN;
+        const bool fits = span_a < (1ll << 28) && span_b < (1ll << 28) && (int64_t)(BM - 1) * g.ldc + BN < (1ll << 28);
+        fast_tile = interior && fits;
+        if (fast_tile) mainloop_fast();
+        else mainloop(std::true_type{});
+    } else {
+        if (interior) mainloop(std::false_type{});
+        else mainloop(std::true_type{});
+    }
 #ifdef VLG_TIMELINE
     tl_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -249,9 +374,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
         g.clock_probe[2 * bid + 1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 #endif
-#ifdef VLG_PRIO_MAIN
-    __builtin_amdgcn_s_setprio(VLG_PRIO_EPI);
-#endif
+    __builtin_amdgcn_s_setprio(2);                   // epilogue: vector work ahead of any younger wave's
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h.
     // 32 lanes of a half write one 128-B row segment per store.
     EO* Cs = static_cast<EO*>(g.C) + (int64_t)split * g.slab_stride;
@@ -279,7 +402,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
                     const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
                     if (GUARD && row0 + ro >= g.M) continue;
                     const int64_t o = base + ro * g.ldc + j * 32;
-                    float v = acc[i][j][r] + bv[j];
+                    float v = acc[i][j][r];
                     if constexpr ((EPI & VLG_EPI_GELU) != 0) { st1(gAuxOut + o, v); v = gelu_f(v); }
                     if constexpr ((EPI & VLG_EPI_RESID) != 0) v += aux[r];
                     if constexpr ((EPI & VLG_EPI_DGELU) != 0) v *= dgelu_f(aux[r]);
@@ -287,7 +410,65 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
                 }
             }
     };
-    if (full) emit(std::false_type{});
+    // fast epilogue: no address arithmetic on the vector ALU (buffer stores: one loop-constant byte offset per thread, the
+    // row in the scalar offset, the 32-column group in the immediate), GELU / dGELU on packed instructions, two rows at a time
+    auto emit_fast = [&]() __attribute__((always_inline)) {
+        const int64_t corner = m0 * g.ldc + n0;
+        const __amdgpu_buffer_rsrc_t dc = vlg_rsrc(Cs + corner);
+        const __amdgpu_buffer_rsrc_t dxin = vlg_rsrc(gAuxIn ? gAuxIn + corner : gA);
+        const __amdgpu_buffer_rsrc_t dxout = vlg_rsrc(gAuxOut ? gAuxOut + corner : Cs + corner);
+        const int vc = ((wm * TM * 32 + 4 * h) * g.ldc + wn * TN * 32 + l31) * 4;
+        const int rowb = g.ldc * 4;
+        constexpr bool AUX = (EPI & (VLG_EPI_RESID | VLG_EPI_DGELU)) != 0;
+        float auxb[2][16];                                               // the auxiliary operand, fetched one 32x32 tile ahead
+        auto fetch = [&](float (&a)[16], int i, int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                a[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dxin, vc + j * 128, (i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, 0));
+        };
+        if constexpr (AUX) fetch(auxb[0], 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int tix = i * TN + j;
+                float (&aux)[16] = auxb[tix & 1];
+                if constexpr (AUX) {
+                    if (tix + 1 < TM * TN) fetch(auxb[(tix + 1) & 1], (tix + 1) / TN, (tix + 1) % TN);
+                }
+                const auto soff = [&](int r) { return (i * 32 + (r & 3) + 8 * (r >> 2)) * rowb; };       // row of register r
+                v2f v[8];                                                // the tile's 16 registers as 8 row pairs (r, r + 1)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = v2f{acc[i][j][2 * q], acc[i][j][2 * q + 1]};
+                if constexpr ((EPI & VLG_EPI_GELU) != 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].x), dxout, vc + j * 128, soff(2 * q), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].y), dxout, vc + j * 128, soff(2 * q + 1), 0);
+                    }
+                    gelu2n<8>(v);
+                }
+                if constexpr ((EPI & VLG_EPI_RESID) != 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += v2f{aux[2 * q], aux[2 * q + 1]};
+                }
+                if constexpr ((EPI & VLG_EPI_DGELU) != 0) {
+                    v2f u[8], d[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) u[q] = v2f{aux[2 * q], aux[2 * q + 1]};
+                    dgelu2n<8>(u, d);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= d[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].x), dc, vc + j * 128, soff(2 * q), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].y), dc, vc + j * 128, soff(2 * q + 1), 0);
+                }
+            }
+    };
+    if (fast_tile) emit_fast();
+    else if (full) emit(std::false_type{});
     else emit(std::true_type{});
 #ifdef VLG_TIMELINE
     if (g.clock_probe) {
@@ -307,7 +488,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
         if (tn == 0) {                                  // block-uniform; the tiles are dead (the main loop ended on a barrier)
             constexpr int PR = TA::PER_ROW, NG = GEMM_THREADS / PR;       // threads per k-row, groups sharing the same rows
             float* red = smem;
-            st4(red + (tid / PR) * BM + 4 * (tid % PR), colacc);
+            st4(red + (tid / PR) * BM + 4 * (tid % PR), make_float4(col_lo.x, col_lo.y, col_hi.x, col_hi.y));
             __syncthreads();
             if (tid < BM && m0 + tid < g.M) {
                 float s = 0.f;
@@ -455,7 +636,8 @@ static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per, bool 
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;
     int64_t p = (M + want - 1) / want;
-    const int kt = bf16 ? 64 : 32;                   // whole K tiles: 32 token rows (fp32 kernel), 64 (bf16 kernel)
+    const int kt = 64;                               // whole K tiles, and an even number of the fp32 kernel's 32-row tiles (its
+                                                     // loop runs them in pairs: an odd count costs one iteration on zeros)
     p = (p + kt - 1) / kt * kt;
     *per = p;
     *splits = (int)((M + p - 1) / p);

@@ -65,6 +65,25 @@ struct Tile {
             else st4(S + (idx << 2), r[i]);
         }
     }
+    // ---- address pieces for loops that keep every per-iteration address out of the vector ALU (gemm.hip, fast path):
+    // a thread's float4 number i sits ISTEP memory rows below its float4 0, in memory and (KC) in LDS alike, so the
+    // per-thread part of every address is a loop constant and the rest is a scalar or an instruction immediate.
+    static constexpr int ISTEP = NT / PER_ROW;                          // memory rows between a thread's consecutive float4
+    static constexpr int SSTEP = KC ? ISTEP * LDK : NT * 4;             // the same step in the LDS tile, floats
+    __device__ static __forceinline__ int voff_bytes(int ld, int tid) { return ((tid / PER_ROW) * ld + ((tid % PER_ROW) << 2)) * 4; }
+    __device__ static __forceinline__ int soff(int tid) { return KC ? (tid / PER_ROW) * LDK + ((tid % PER_ROW) << 2) : (tid << 2); }
+    __device__ static __forceinline__ int roff(int row, int h) { return KC ? row * LDK + 4 * h : 4 * h * BR + row; }
+    // fragment of the 32-row group `grp` for chunk s, from base = tile + roff(first row of the wave, h): all offsets immediates
+    // (grp and s are compile-time constants once the caller's loops are unrolled)
+    __device__ static __forceinline__ void frag_at(float (&f)[4], const float* base, int grp, int s) {
+        if constexpr (KC) {
+            const float4 t = ld4(base + grp * 32 * LDK + 8 * s);
+            f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = base[(8 * s + j) * BR + grp * 32];
+        }
+    }
     // 4 fragment values of tile row `row` for chunk s, lane half h:  k = 8s + 4h + j
     __device__ static __forceinline__ void frag(float (&f)[4], const float* S, int row, int s, int h) {
         if constexpr (KC) {
