@@ -167,6 +167,41 @@ def test_linear_fwd_gelu_and_resid(H, dev, M, N, K):
     assert_close(c, (pre + r.double()).float(), what="linear + residual")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 1024, 256), (520, 384, 96)])
+def test_linear_gelu_grad_saved_and_mul(H, dev, M, N, K):
+    """VLG_EPI_GELU_GRAD: the first FFN projection stores gelu'(pre) instead of pre;  VLG_EPI_MUL: the data gradient of the
+    second projection multiplies by it - together they must give what VLG_EPI_GELU / VLG_EPI_DGELU give (interior and
+    edge tiles, even and odd K-tile counts)."""
+    torch.manual_seed(11)
+    a, w, b = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K) * 1.5, torch.randn(N)
+    pre = F.linear(a.double(), w.double(), b.double())
+    uu = pre.clone().requires_grad_(True)
+    F.gelu(uu).sum().backward()
+    ad, wd, bd = a.to(dev), w.to(dev), b.to(dev)
+    c = torch.full((M, N), float("nan"), device=dev)
+    dsave = torch.full((M, N), float("nan"), device=dev)
+    H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, dsave.data_ptr(),
+           M, N, K, H.EPI_BIAS | H.EPI_GELU | H.EPI_GELU_GRAD, stream())
+    assert_close(c, F.gelu(pre).float(), what="ffn gelu (grad saved)")
+    assert_close(dsave, uu.grad.float(), rtol=1e-4, atol=1e-5, what="saved gelu'")
+    # data gradient of the second projection: dU = (dY . W2) * saved
+    K2 = 128
+    dy, w2 = torch.randn(M, K2), torch.randn(K2, N) / math.sqrt(K2)
+    dyd, w2d = dy.to(dev), w2.to(dev)
+    du = torch.full((M, N), float("nan"), device=dev)
+    H.call("vlg_linear_dgrad", dyd.data_ptr(), K2, w2d.data_ptr(), N, du.data_ptr(), N, dsave.data_ptr(), M, K2, N,
+           H.EPI_MUL, stream())
+    want = (dy.double() @ w2.double()) * uu.grad
+    assert_close(du, want.float(), rtol=1e-4, atol=1e-5, what="dgrad * saved gelu'")
+    # the other modes refuse the flags instead of ignoring them
+    lib = H.load()
+    assert lib.vlg_linear_fwd(ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, dsave.data_ptr(),
+                              M, N, K, H.EPI_BIAS | H.EPI_GELU | H.EPI_GELU_GRAD | H.EPI_BF16, stream()) == 1001
+    assert lib.vlg_linear_dgrad(dyd.data_ptr(), K2, w2d.data_ptr(), N, du.data_ptr(), N, dsave.data_ptr(), M, K2, N,
+                                H.EPI_MUL | H.EPI_SPLIT3, stream()) == 1001
+    assert lib.vlg_linear_dgrad(dyd.data_ptr(), K2, w2d.data_ptr(), N, du.data_ptr(), N, 0, M, K2, N, H.EPI_MUL, stream()) == 1001
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 1024), (300, 128, 512), (1000, 256, 96)])
 def test_linear_gelu_on_load(H, dev, M, N, K):
     """VLG_EPI_ACT_GELU: the activation operand holds PRE-activations u and gelu(u) is formed while the tile is staged -

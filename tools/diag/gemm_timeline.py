@@ -30,6 +30,8 @@ CASES = {
     "proj": (512, lambda: hip.call("vlg_linear_fwd", P(x_d), d, P(w_proj), d, P(bias), P(y_d), d, P(x_d), 0, M, d, d, EPI_BIAS | EPI_RESID, S)),
     "ff2": (512, lambda: hip.call("vlg_linear_fwd", P(x_ff), ff, P(w_ff2), ff, P(bias), P(y_d), d, P(x_d), 0, M, d, ff, EPI_BIAS | EPI_RESID, S)),
     "dgelu": (2048, lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(y_ff), ff, P(x_ff2), M, d, ff, EPI_DGELU, S)),
+    "mul": (2048, lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(y_ff), ff, P(x_ff2), M, d, ff, 2048, S)),
+    "dplain": (2048, lambda: hip.call("vlg_linear_dgrad", P(x_d), d, P(w_ff2), ff, P(y_ff), ff, 0, M, d, ff, EPI_NONE, S)),
     "dqkv": (512, lambda: hip.call("vlg_linear_dgrad", P(x_3d), 3 * d, P(w_qkv), d, P(y_d), d, 0, M, 3 * d, d, EPI_NONE, S)),
     "wgrad": (512, lambda: hip.call("vlg_linear_wgrad", P(x_ff), ff, P(x_d), d, P(slabs), ff * d + ff, slabs.numel(), M, ff, d, 0, S)),
 }

@@ -158,6 +158,27 @@ __device__ __forceinline__ void gelu2n(v2f (&x)[N]) {            // in place
     for (int n = 0; n < N; ++n) x[n] = v2f{x[n].x - fabsf(tail[n].x), x[n].y - fabsf(tail[n].y)};
     VLG_STEP();
 }
+// x -> gelu(x) in place, d = gelu'(x): the derivative costs five more steps on top of the shared exp / reciprocal / polynomial
+template <int N>
+__device__ __forceinline__ void gelu_both2n(v2f (&x)[N], v2f (&d)[N]) {
+    v2f tail[N], e[N];
+    gelu_parts2n<N>(x, tail, e);
+#pragma unroll
+    for (int n = 0; n < N; ++n) { d[n] = v2(0.5f) - tail[n]; e[n] = x[n] * e[n]; tail[n] = x[n] * tail[n]; }
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) d[n] = v2f{__builtin_copysignf(d[n].x, x[n].x), __builtin_copysignf(d[n].y, x[n].y)};
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) { d[n] = d[n] + v2(0.5f); x[n] = v2f{relu_f(x[n].x), relu_f(x[n].y)}; }
+    VLG_STEP();
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        d[n] = __builtin_elementwise_fma(e[n], v2(0.39894228040143268f), d[n]);
+        x[n] = v2f{x[n].x - fabsf(tail[n].x), x[n].y - fabsf(tail[n].y)};
+    }
+    VLG_STEP();
+}
 template <int N>
 __device__ __forceinline__ void dgelu2n(const v2f (&x)[N], v2f (&d)[N]) {
     v2f tail[N], e[N];

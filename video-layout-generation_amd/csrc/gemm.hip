@@ -268,8 +268,18 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
         float* const bw = smem + 2 * TA::FLOATS + TB::soff(tid);
         const float* const ar = smem + TA::roff(wm * TM * 32 + l31, h);
         const float* const br = smem + 2 * TA::FLOATS + TB::roff(wn * TN * 32 + l31, h);
-        v4f xa[TA::NV], xb[TB::NV];
-        auto load = [&](int t) __attribute__((always_inline)) {
+        // DEPTH K tiles travel global -> register at once.  Two of them: a tile is requested two iterations before it is
+        // written to LDS, so the loop rides out ~3.5 us of a blocked memory pipeline - the CU's vector-memory path is shared
+        // with the co-resident block, whose epilogue bursts (64 KB of stores, 64 KB of auxiliary loads that miss to HBM)
+        // otherwise stall this block's next tile behind them with the matrix pipe idle.
+#ifndef VLG_GEMM_DEPTH
+#define VLG_GEMM_DEPTH 1
+#endif
+        constexpr int DEPTH = VLG_GEMM_DEPTH;
+        v4f xas[DEPTH][TA::NV], xbs[DEPTH][TB::NV];
+        auto load = [&](int t, int set) __attribute__((always_inline)) {
+            v4f (&xa)[TA::NV] = xas[set];
+            v4f (&xb)[TB::NV] = xbs[set];
             // K tiles past the end read as zeros: through the empty descriptor (K-contiguous operand) or past the end of
             // the operand's own descriptor (contraction-major operand)
             const bool in = t < nk;
@@ -279,7 +289,9 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
 #pragma unroll
             for (int i = 0; i < TB::NV; ++i) xb[i] = __builtin_amdgcn_raw_buffer_load_b128(ub, vb, t * b_ks + i * b_is, 0);
         };
-        auto store = [&](int c) __attribute__((always_inline)) {
+        auto store = [&](int c, int set) __attribute__((always_inline)) {
+            v4f (&xa)[TA::NV] = xas[set];
+            v4f (&xb)[TB::NV] = xbs[set];
             if constexpr (COLSUM) {
 #pragma unroll
                 for (int i = 0; i < TA::NV; ++i) {
@@ -315,9 +327,10 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
                     ldf(fa[0], fb[0], cur ^ 1, 0);
                 }
                 VLG_SCHED_FENCE();
-                if (s == SS) {
-                    store(cur ^ 1);
-                    load(kt + 2);
+                if (s == SS) {                               // tile kt + 1 -> LDS, its registers take tile kt + 1 + DEPTH
+                    const int set = DEPTH == 2 ? (cur ^ 1) : 0;
+                    store(cur ^ 1, set);
+                    load(kt + 1 + DEPTH, set);
                 }
                 mma(fa[s & 1], fb[s & 1]);
                 if (s == SS) {
@@ -337,9 +350,10 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
             }
         };
         // (an odd nk runs one iteration on a zero tile)
-        load(0);
-        store(0);
-        load(1);
+        load(0, 0);
+        store(0, 0);
+        if constexpr (DEPTH == 2) { load(1, 1); load(2, 0); }
+        else load(1, 0);
         __syncthreads();
         ldf(fa[0], fb[0], 0, 0);
         __builtin_amdgcn_s_setprio(0);
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
             for (int j = 0; j < TN; ++j) {
                 if (GUARD && col0 + j * 32 >= g.N) continue;
                 float aux[16];
-                if constexpr ((EPI & (VLG_EPI_RESID | VLG_EPI_DGELU)) != 0) {
+                if constexpr ((EPI & (VLG_EPI_RESID | VLG_EPI_DGELU | VLG_EPI_MUL)) != 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
@@ -403,9 +417,20 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
                     if (GUARD && row0 + ro >= g.M) continue;
                     const int64_t o = base + ro * g.ldc + j * 32;
                     float v = acc[i][j][r];
-                    if constexpr ((EPI & VLG_EPI_GELU) != 0) { st1(gAuxOut + o, v); v = gelu_f(v); }
+                    if constexpr ((EPI & VLG_EPI_GELU) != 0) {
+                        if constexpr ((EPI & VLG_EPI_GELU_GRAD) != 0) {
+                            float c, pd;
+                            gelu_parts(v, c, pd);
+                            st1(gAuxOut + o, c + v * pd);
+                            v *= c;
+                        } else {
+                            st1(gAuxOut + o, v);
+                            v = gelu_f(v);
+                        }
+                    }
                     if constexpr ((EPI & VLG_EPI_RESID) != 0) v += aux[r];
                     if constexpr ((EPI & VLG_EPI_DGELU) != 0) v *= dgelu_f(aux[r]);
+                    if constexpr ((EPI & VLG_EPI_MUL) != 0) v *= aux[r];
                     st1(Cs + o, v);
                 }
             }
@@ -419,28 +444,48 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
         const __amdgpu_buffer_rsrc_t dxout = vlg_rsrc(gAuxOut ? gAuxOut + corner : Cs + corner);
         const int vc = ((wm * TM * 32 + 4 * h) * g.ldc + wn * TN * 32 + l31) * 4;
         const int rowb = g.ldc * 4;
-        constexpr bool AUX = (EPI & (VLG_EPI_RESID | VLG_EPI_DGELU)) != 0;
-        float auxb[2][16];                                               // the auxiliary operand, fetched one 32x32 tile ahead
+        constexpr bool AUX = (EPI & (VLG_EPI_RESID | VLG_EPI_DGELU | VLG_EPI_MUL)) != 0;
+        // the auxiliary operand: ALL of it is requested before the first store where the registers allow (BK = 32: two blocks
+        // per CU, 256 registers) - loads and stores retire through one in-order counter, so a load issued behind a tile's
+        // stores is not usable before those stores have landed; with three blocks per CU (BK = 16) one tile ahead
+        constexpr bool AUX_ALL = BK == 32;
+        constexpr int NAUX = AUX_ALL ? TM * TN : 2;
+        float auxb[NAUX][16];
         auto fetch = [&](float (&a)[16], int i, int j) __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 a[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dxin, vc + j * 128, (i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, 0));
         };
-        if constexpr (AUX) fetch(auxb[0], 0, 0);
+        if constexpr (AUX) {
+            if constexpr (AUX_ALL) {
+#pragma unroll
+                for (int t = 0; t < TM * TN; ++t) fetch(auxb[t], t / TN, t % TN);
+            } else {
+                fetch(auxb[0], 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int tix = i * TN + j;
-                float (&aux)[16] = auxb[tix & 1];
-                if constexpr (AUX) {
+                float (&aux)[16] = auxb[AUX_ALL ? tix : (tix & 1)];
+                if constexpr (AUX && !AUX_ALL) {
                     if (tix + 1 < TM * TN) fetch(auxb[(tix + 1) & 1], (tix + 1) / TN, (tix + 1) % TN);
                 }
                 const auto soff = [&](int r) { return (i * 32 + (r & 3) + 8 * (r >> 2)) * rowb; };       // row of register r
                 v2f v[8];                                                // the tile's 16 registers as 8 row pairs (r, r + 1)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = v2f{acc[i][j][2 * q], acc[i][j][2 * q + 1]};
-                if constexpr ((EPI & VLG_EPI_GELU) != 0) {
+                if constexpr ((EPI & VLG_EPI_GELU) != 0 && (EPI & VLG_EPI_GELU_GRAD) != 0) {
+                    v2f dv[8];
+                    gelu_both2n<8>(v, dv);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv[q].x), dxout, vc + j * 128, soff(2 * q), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv[q].y), dxout, vc + j * 128, soff(2 * q + 1), 0);
+                    }
+                } else if constexpr ((EPI & VLG_EPI_GELU) != 0) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].x), dxout, vc + j * 128, soff(2 * q), 0);
@@ -451,6 +496,10 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
                 if constexpr ((EPI & VLG_EPI_RESID) != 0) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] += v2f{aux[2 * q], aux[2 * q + 1]};
+                }
+                if constexpr ((EPI & VLG_EPI_MUL) != 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= v2f{aux[2 * q], aux[2 * q + 1]};
                 }
                 if constexpr ((EPI & VLG_EPI_DGELU) != 0) {
                     v2f u[8], d[8];
@@ -509,14 +558,15 @@ extern "C" void vlg_debug_set_clock_probe(unsigned long long* p) { vlg_gemm_cloc
 // is 8-11 % faster when the epilogue is heavy (GELU / dGELU: two extra 134 MB streams), because more
 // resident blocks de-synchronise the store bursts from the other blocks' MFMA phases.
 // VLG_GEMM_BK=16|32 forces one value for A/B runs.
+static int vlg_gemm_bk_forced = -1;
 static int gemm_bk_override() {
-    static int v = -1;
-    if (v < 0) {
+    if (vlg_gemm_bk_forced < 0) {
         const char* e = getenv("VLG_GEMM_BK");
-        v = e ? atoi(e) : 0;
+        vlg_gemm_bk_forced = e ? atoi(e) : 0;
     }
-    return v;
+    return vlg_gemm_bk_forced;
 }
+extern "C" void vlg_debug_set_gemm_bk(int bk) { vlg_gemm_bk_forced = (bk == 16 || bk == 32) ? bk : 0; }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
 static int launch_gemm(GemmArgs g, hipStream_t s) {
@@ -571,6 +621,9 @@ extern "C" int vlg_linear_fwd(const void* A, int lda, const void* W, int ldw, co
     if ((epilogue & VLG_EPI_BIAS) && !bias) return VLG_ERR_SHAPE;
     if ((epilogue & (VLG_EPI_RESID | VLG_EPI_DGELU)) && !aux_in) return VLG_ERR_SHAPE;
     if ((epilogue & VLG_EPI_GELU) && !aux_out) return VLG_ERR_SHAPE;
+    if ((epilogue & VLG_EPI_MUL) != 0) return VLG_ERR_SHAPE;                                          // a dgrad epilogue
+    if ((epilogue & VLG_EPI_GELU_GRAD) && (bf16 || split3 || epilogue != (VLG_EPI_BIAS | VLG_EPI_GELU | VLG_EPI_GELU_GRAD)))
+        return VLG_ERR_SHAPE;                                                                         // native fp32 path only
     const bool narrow = N <= 32;
     const bool act_gelu = (epilogue & VLG_EPI_ACT_GELU) != 0;
     epilogue &= ~VLG_EPI_ACT_GELU;
@@ -589,6 +642,8 @@ extern "C" int vlg_linear_fwd(const void* A, int lda, const void* W, int ldw, co
                           : launch_gemm<128, 128, true, true, VLG_EPI_BIAS, false>(g, s);
         case VLG_EPI_BIAS | VLG_EPI_GELU:
             return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false>(g, s);
+        case VLG_EPI_BIAS | VLG_EPI_GELU | VLG_EPI_GELU_GRAD:
+            return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU | VLG_EPI_GELU_GRAD, false>(g, s);
         case VLG_EPI_BIAS | VLG_EPI_RESID:
             return launch_gemm<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false>(g, s);
         default:
@@ -612,7 +667,8 @@ extern "C" int vlg_linear_dgrad(const void* dY, int ldy, const void* W, int ldw,
     if (split3 && (bf16 || io != 0)) return VLG_ERR_SHAPE;
     if (io != 0 && !bf16) return VLG_ERR_SHAPE;
     if (((io & 1) && (ldy & 7)) || ((io & 2) && (ldw & 7))) return VLG_ERR_ALIGN;
-    if (epilogue == VLG_EPI_DGELU && !aux_in) return VLG_ERR_SHAPE;
+    if ((epilogue == VLG_EPI_DGELU || epilogue == VLG_EPI_MUL) && !aux_in) return VLG_ERR_SHAPE;
+    if (epilogue == VLG_EPI_MUL && (bf16 || split3)) return VLG_ERR_SHAPE;                            // native fp32 path only
     if (bf16) return vlg_gemm16_dgrad(g, epilogue, io, s);
     if (split3) return vlg_gemm_split_dgrad(g, epilogue, s);
     switch (epilogue) {
@@ -621,6 +677,8 @@ extern "C" int vlg_linear_dgrad(const void* dY, int ldy, const void* W, int ldw,
         case VLG_EPI_DGELU:
             if (!aux_in) return VLG_ERR_SHAPE;
             return launch_gemm<128, 128, true, false, VLG_EPI_DGELU, false>(g, s);
+        case VLG_EPI_MUL:
+            return launch_gemm<128, 128, true, false, VLG_EPI_MUL, false>(g, s);
         default:
             return VLG_ERR_SHAPE;
     }

@@ -80,6 +80,12 @@ class LayoutEngine:
         # optional (native fp32 only): gelu(u) is never stored - the FFN's first projection writes the pre-activation u
         # only and the second projection / its weight gradient apply GELU while staging their operand (VLG_EPI_ACT_GELU)
         self.gelu_on_load = False      # measured slower end to end (GEMM notes): the recomputation is not hidden
+        # native fp32: the FFN's first projection stores gelu'(u) in the pre-activation buffer instead of u (VLG_EPI_GELU_GRAD;
+        # nothing else reads u) and the second projection's data gradient multiplies by it (VLG_EPI_MUL): ~20 vector
+        # instructions per element less in a kernel that pays for each of them in matrix time (csrc/common.h)
+        self.gelu_grad_saved = precision == "fp32" and not self.gelu_on_load and os.environ.get("VLG_GELU_GRAD_SAVED", "1") != "0"
+        self._epi_ff1 = EPI_BIAS | EPI_GELU | (hip.EPI_GELU_GRAD if self.gelu_grad_saved else 0)
+        self._epi_dff2 = hip.EPI_MUL if self.gelu_grad_saved else EPI_DGELU
         self._sfx = "_bf16" if self.bf16_store else ""
         hip.load()                                   # fail loudly before touching the GPU
         if device.type != "cuda":
@@ -315,7 +321,7 @@ class LayoutEngine:
                              EPI_BIAS | EPI_RESID | EPI_ACT_GELU, aux_in=self.xmid[l])
             else:
                 self._linear(self.h2[l], self.pw(pre + "ff1_w"), self.p(pre + "ff1_b"), self.gl[l], M, ff, d,
-                             EPI_BIAS | EPI_GELU, aux_out=self.u[l])
+                             self._epi_ff1, aux_out=self.u[l])
                 self._linear(self.gl[l], self.pw(pre + "ff2_w"), self.p(pre + "ff2_b"), self.x[l + 1], M, d, ff,
                              EPI_BIAS | EPI_RESID, aux_in=self.xmid[l])
         L = cfg.n_layers
@@ -395,7 +401,7 @@ class LayoutEngine:
             else:
                 on_side(("dx",), lambda: self._wgrad(self.dx, self.gl[l], pre + "ff2_w", M, d, ff))
             before_write("du")
-            self._dgrad(self.dx, self.pw(pre + "ff2_w"), self.du, M, d, ff, EPI_DGELU, aux_in=self.u[l])
+            self._dgrad(self.dx, self.pw(pre + "ff2_w"), self.du, M, d, ff, self._epi_dff2, aux_in=self.u[l])
             on_side(("du",), lambda: self._wgrad(self.du, self.h2[l], pre + "ff1_w", M, ff, d))
             self._dgrad(self.du, self.pw(pre + "ff1_w"), self.dh, M, ff, d)
             before_write("dx")
@@ -451,7 +457,7 @@ class LayoutEngine:
         for l in reversed(range(cfg.n_layers)):
             pre = "l%d." % l
             self._wgrad(self.dx, self.gl[l], pre + "ff2_w", M, d, ff)
-            self._dgrad(self.dx, self.pw(pre + "ff2_w"), self.du, M, d, ff, EPI_DGELU, aux_in=self.u[l])
+            self._dgrad(self.dx, self.pw(pre + "ff2_w"), self.du, M, d, ff, self._epi_dff2, aux_in=self.u[l])
             self._dgrad(self.du, self.pw(pre + "ff1_w"), self.dh, M, ff, d)
             beside(lambda: self._ln_bwd(self.dh, self.xmid[l], self.stats[2 * l + 1], pre + "ln2_g", self.dx, self.dx, M),
                    lambda: self._wgrad(self.du, self.h2[l], pre + "ff1_w", M, ff, d))

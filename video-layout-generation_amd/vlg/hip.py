@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("VLG_HIP_LIB") or os.path.join(os.path.dirname(_HERE),
 EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_BF16 = 0, 1, 2, 4, 8, 16
 EPI_A_BF16, EPI_B_BF16, EPI_OUT_BF16, EPI_SPLIT3 = 32, 64, 128, 256      # bf16 activation storage (include/vlg_hip.h)
 EPI_ACT_GELU = 512                                                       # activation operand = gelu(stored), applied on load
+EPI_GELU_GRAD, EPI_MUL = 1024, 2048                                      # aux_out = gelu'(pre);  dgrad: C = acc * aux_in
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 
@@ -25,6 +26,7 @@ SIGNATURES = {
     "vlg_abi_version": (I, []),
     "vlg_build_arch": (c_char_p, []),
     "vlg_debug_set_clock_probe": (None, [P]),
+    "vlg_debug_set_gemm_bk": (None, [I]),
     "vlg_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "vlg_embed_bwd_slabs": (I, []),
     "vlg_embed_bwd": (I, [P, P, P, P, L, L, I, I, I, I, I, P]),
