@@ -47,6 +47,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t vlg_rsrc(const void* p, int by
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+// Epilogue pacing.  The CU's vector-memory pipeline is one FIFO for all its waves and takes ~5 cycles per 128-B line
+// (tools/micro/mfma_f32_valu_share.hip mem): a 64 KB epilogue burst (512 lines, 1024 with an auxiliary operand) holds it for
+// 1-2 us, and the co-resident block - whose waves issue in order - stalls at the ISSUE of its next tile's loads with the
+// matrix pipe idle (per-CU timelines: +1.3 us per block behind a plain store epilogue, +3.4 us behind loads + stores; a
+// deeper tile prefetch does not help, the wave never gets to issue it).  So the epilogue sleeps between small groups of
+// memory instructions: it lasts longer, but the FIFO stays short and the other block's loads slip in.
+#ifndef VLG_EPI_PACE
+#define VLG_EPI_PACE 1          /* s_sleep argument (x 64 cycles) behind every VLG_EPI_PACE_EVERY memory instructions; 0 = off */
+#endif
+#ifndef VLG_EPI_PACE_EVERY
+#define VLG_EPI_PACE_EVERY 2
+#endif
+__device__ __forceinline__ void vlg_epi_pace(int issued) {
+#if VLG_EPI_PACE > 0
+    if (issued % VLG_EPI_PACE_EVERY == 0) __builtin_amdgcn_s_sleep(VLG_EPI_PACE);
+#endif
+}
+
 #ifdef VLG_NO_SCHED_FENCE
 #define VLG_SCHED_FENCE()
 #else
@@ -55,12 +73,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t vlg_rsrc(const void* p, int by
 
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM>
 __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(const GemmArgs g) {
-    // A new block's waves share their SIMDs with an OLDER block that issues MFMAs back to back, and the vector ALU serves
-    // the oldest wave first: at equal priority the newcomer's index arithmetic - and with it its first tile loads - is
-    // starved until the older block leaves its main loop (per-CU timelines: a block's first stamp coincides with its
-    // neighbour's loop end), and every block then waits out its first loads with the matrix pipe idle.  So the prologue
-    // runs at raised priority (its ~130 vector instructions slip in between the neighbour's MFMAs) and drops back in
-    // front of its own main loop.
+    // Raised priority until the main loop starts.  It does NOT get this block's vector instructions past an older block's
+    // MFMA stream (the vector ALU serves the oldest wave that has a matrix or vector instruction ready, whatever s_setprio
+    // says: tools/micro/mfma_f32_valu_share.hip prio / two), but the prologue's loads and LDS writes are issued ahead of the
+    // neighbour's: measured 3-5 % per launch.
     __builtin_amdgcn_s_setprio(3);
     using EO = float;
     const float* const gA = static_cast<const float*>(g.A);
@@ -82,10 +98,15 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    const int ntile = g.tiles_m * g.tiles_n;
+    // N tiles per block: the fast path of the BK = 32 kernels without bias-gradient sums (the host sets it); a compile-time 1
+    // elsewhere, so those kernels have no loop around [main loop, epilogue]
+    constexpr bool CHAIN = BM == 128 && BN == 128 && BK == 32 && !COLSUM && (EPI & ((1 << 20) | (1 << 21))) == 0;
+    const int run = (CHAIN && g.run > 1) ? g.run : 1;
+    const int tng = g.tiles_n / run;
+    const int ntile = g.tiles_m * tng;
     const int split = swz / ntile;
     const int tile = swz - split * ntile;
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int tm = tile / tng, tn = (tile - tm * tng) * run;
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
     const int64_t kbeg = (int64_t)split * g.kc_per_split;
@@ -116,18 +137,27 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
     };
     // the accumulators START from the bias (a lane's 16 accumulators of a 32x32 tile share one column): no vector
     // instruction is spent on it in the epilogue, where every one of them costs matrix time (see common.h, gelu2)
+    float bv[TN];
+    auto load_bias = [&](int n0v) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        float bvj = 0.f;
-        if constexpr ((EPI & VLG_EPI_BIAS) != 0) {
-            const int col = n0 + (wn * TN + j) * 32 + l31;
-            bvj = g.bias[col < g.N ? col : g.N - 1];
+        for (int j = 0; j < TN; ++j) {
+            bv[j] = 0.f;
+            if constexpr ((EPI & VLG_EPI_BIAS) != 0) {
+                const int col = n0v + (wn * TN + j) * 32 + l31;
+                bv[j] = g.bias[col < g.N ? col : g.N - 1];
+            }
         }
+    };
+    auto init_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = bvj;
-    }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];
+    };
+    load_bias(n0);
+    init_acc();
 
 #ifndef VLG_TIMELINE
     unsigned long long t0 = 0, r0 = 0;
@@ -251,12 +281,23 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
     // advance and the float4 number in the SCALAR offset - and two iterations are unrolled so the LDS buffer is a compile-
     // time constant and every LDS address is one loop-constant register plus an instruction immediate.
     constexpr bool FAST = BM == 128 && BN == 128 && (EPI & (GEMM_A_GELU | GEMM_B_GELU)) == 0;
-    auto mainloop_fast = [&]() __attribute__((always_inline)) {
+    // A block may compute `run` consecutive N tiles of one row panel back to back (multi-round launches): the K loop
+    // then simply CONTINUES into the next tile - the loads its last two iterations issue are the next tile's first two K
+    // tiles, the LDS write of its last iteration is the next tile's tile 0 and the fragments read behind its last
+    // barrier are the next tile's first - so only the epilogue separates the MFMA streams of two tiles.  (A block that
+    // starts while an older one streams MFMAs cannot do that: the vector ALU serves the MFMA stream first - s_setprio
+    // does not change it, tools/micro/mfma_f32_valu_share.hip prio - so its index arithmetic, and with it its first loads,
+    // wait for the neighbour's loop end: per-CU timelines show 1.3-3.4 us of idle matrix pipe per block.)
+#ifndef VLG_GEMM_DEPTH
+#define VLG_GEMM_DEPTH 1     /* 2 measured: no gain (tools/ab/gemm_ab.py), +16..32 registers */
+#endif
+    constexpr int DEPTH = VLG_GEMM_DEPTH;
+    v4f xas[DEPTH][TA::NV], xbs[DEPTH][TB::NV];      // staging registers and fragment sets live across the tiles of a run
+    float ffa[2][TM][4], ffb[2][TN][4];
+    auto mainloop_fast = [&](int n0v, bool first, bool has_next) __attribute__((always_inline)) {
         const float* pa = A_KC ? gA + m0 * g.lda + kbeg : gA + kbeg * g.lda + m0;
-        const float* pb = B_KC ? gB + (int64_t)n0 * g.ldb + kbeg : gB + kbeg * g.ldb + n0;
-        // a contraction-major operand's descriptor ends with the K range of this block: the loads the last two iterations
-        // issue beyond it return zeros (exact no-ops in the bias-gradient sums); a K-contiguous operand re-reads its last
-        // K tile instead (clamped tile index)
+        const float* pb = B_KC ? gB + (int64_t)n0v * g.ldb + kbeg : gB + kbeg * g.ldb + n0v;
+        // a contraction-major operand's descriptor ends with the K range of this block: loads beyond it return zeros
         const int ext_b = (int)(kend - kbeg);
         const __amdgpu_buffer_rsrc_t da = A_KC ? vlg_rsrc(pa) : vlg_rsrc(pa, ext_b * g.lda * 4);
         const __amdgpu_buffer_rsrc_t db = B_KC ? vlg_rsrc(pb) : vlg_rsrc(pb, ext_b * g.ldb * 4);
@@ -264,30 +305,31 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
         const int va = TA::voff_bytes(g.lda, tid), vb = TB::voff_bytes(g.ldb, tid);
         const int a_is = TA::ISTEP * g.lda * 4, b_is = TB::ISTEP * g.ldb * 4;              // bytes between a thread's float4
         const int a_ks = A_KC ? BK * 4 : BK * g.lda * 4, b_ks = B_KC ? BK * 4 : BK * g.ldb * 4;   // bytes per K tile
+        const int b_next = B_KC ? BN * g.ldb * 4 : BN * 4;                                  // bytes to the next N tile of B
         float* const aw = smem + TA::soff(tid);
         float* const bw = smem + 2 * TA::FLOATS + TB::soff(tid);
-        const float* const ar = smem + TA::roff(wm * TM * 32 + l31, h);
-        const float* const br = smem + 2 * TA::FLOATS + TB::roff(wn * TN * 32 + l31, h);
-        // DEPTH K tiles travel global -> register at once.  Two of them: a tile is requested two iterations before it is
-        // written to LDS, so the loop rides out ~3.5 us of a blocked memory pipeline - the CU's vector-memory path is shared
-        // with the co-resident block, whose epilogue bursts (64 KB of stores, 64 KB of auxiliary loads that miss to HBM)
-        // otherwise stall this block's next tile behind them with the matrix pipe idle.
-#ifndef VLG_GEMM_DEPTH
-#define VLG_GEMM_DEPTH 1
-#endif
-        constexpr int DEPTH = VLG_GEMM_DEPTH;
-        v4f xas[DEPTH][TA::NV], xbs[DEPTH][TB::NV];
+        // one read base per 32-row group: every fragment offset of a contraction-major tile is then a multiple of 256 B below
+        // 64 KB, which ds_read2st64_b32 encodes (two bases short, hipcc re-derives addresses with v_add_u32 inside the loop)
+        const float* ar[TM];
+        const float* br[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ar[i] = smem + TA::roff((wm * TM + i) * 32 + l31, h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) br[j] = smem + 2 * TA::FLOATS + TB::roff((wn * TN + j) * 32 + l31, h);
         auto load = [&](int t, int set) __attribute__((always_inline)) {
             v4f (&xa)[TA::NV] = xas[set];
             v4f (&xb)[TB::NV] = xbs[set];
-            // K tiles past the end read as zeros: through the empty descriptor (K-contiguous operand) or past the end of
-            // the operand's own descriptor (contraction-major operand)
-            const bool in = t < nk;
-            const __amdgpu_buffer_rsrc_t ua = (A_KC && !in) ? dza : da, ub = (B_KC && !in) ? dzb : db;
+            // K tiles past the end: the NEXT tile of the run (same A panel from its start, B one N tile further), or - no next
+            // tile - zeros: through the empty descriptor (K-contiguous operand) or past the end of the operand's own
+            // descriptor (contraction-major operand); an odd nk runs one iteration on such a zero tile
+            const bool in = t < nk, wrap = !in && has_next;
+            const int tw = wrap ? t - nk : t;
+            const __amdgpu_buffer_rsrc_t ua = (A_KC && !in && !wrap) ? dza : da, ub = (B_KC && !in && !wrap) ? dzb : db;
+            const int oa = tw * a_ks, ob = tw * b_ks + (wrap ? b_next : 0);
 #pragma unroll
-            for (int i = 0; i < TA::NV; ++i) xa[i] = __builtin_amdgcn_raw_buffer_load_b128(ua, va, t * a_ks + i * a_is, 0);
+            for (int i = 0; i < TA::NV; ++i) xa[i] = __builtin_amdgcn_raw_buffer_load_b128(ua, va, oa + i * a_is, 0);
 #pragma unroll
-            for (int i = 0; i < TB::NV; ++i) xb[i] = __builtin_amdgcn_raw_buffer_load_b128(ub, vb, t * b_ks + i * b_is, 0);
+            for (int i = 0; i < TB::NV; ++i) xb[i] = __builtin_amdgcn_raw_buffer_load_b128(ub, vb, ob + i * b_is, 0);
         };
         auto store = [&](int c, int set) __attribute__((always_inline)) {
             v4f (&xa)[TA::NV] = xas[set];
@@ -308,23 +350,24 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
         };
         auto ldf = [&](float (&a)[TM][4], float (&b)[TN][4], int c, int s) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) TA::frag_at(a[i], ar + c * TA::FLOATS, i, s);
+            for (int i = 0; i < TM; ++i) TA::frag_at(a[i], ar[i] + c * TA::FLOATS, 0, s);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) TB::frag_at(b[j], br + c * TB::FLOATS, j, s);
+            for (int j = 0; j < TN; ++j) TB::frag_at(b[j], br[j] + c * TB::FLOATS, 0, s);
         };
         constexpr int SS = NCH / 2 - 1;
-        float fa[2][TM][4], fb[2][TN][4];
         // cur is a literal at every call site (the lambda is always inlined), so cur * FLOATS folds into the immediates.
-        // There are NO peeled tail iterations: the last two iterations run the same code - their loads return zeros, their
-        // LDS writes go to the buffer nobody reads any more and the fragments read behind the last barrier are dropped.  One copy of the iteration per buffer parity keeps the code small and the
-        // register allocation tight (seven inlined tail copies cost 60+ registers and spills).
+        // There are NO peeled tail iterations: the last two iterations run the same code - their loads fetch the next tile of
+        // the run (or zeros), their LDS writes go to the buffer nobody reads any more (or hold the next tile's first K
+        // tile) and the fragments read behind the last barrier are dropped (or are the next tile's first).  One copy of the
+        // iteration per buffer parity keeps the code small and the register allocation tight (seven inlined tail copies
+        // cost 60+ registers and spills).
         auto iter = [&](int kt, int cur) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < NCH; ++s) {
-                if (s + 1 < NCH) ldf(fa[(s + 1) & 1], fb[(s + 1) & 1], cur, s + 1);
+                if (s + 1 < NCH) ldf(ffa[(s + 1) & 1], ffb[(s + 1) & 1], cur, s + 1);
                 if (s == NCH - 1) {
                     __syncthreads();
-                    ldf(fa[0], fb[0], cur ^ 1, 0);
+                    ldf(ffa[0], ffb[0], cur ^ 1, 0);
                 }
                 VLG_SCHED_FENCE();
                 if (s == SS) {                               // tile kt + 1 -> LDS, its registers take tile kt + 1 + DEPTH
@@ -332,7 +375,7 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
                     store(cur ^ 1, set);
                     load(kt + 1 + DEPTH, set);
                 }
-                mma(fa[s & 1], fb[s & 1]);
+                mma(ffa[s & 1], ffb[s & 1]);
                 if (s == SS) {
                     constexpr int N_MFMA = 4 * TM * TN, N_ST = TA::NV + TB::NV, N_LD = TA::NV + TB::NV;
                     constexpr int PER = (N_ST + N_LD + N_MFMA - 1) / N_MFMA;
@@ -349,19 +392,24 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
                 }
             }
         };
-        // (an odd nk runs one iteration on a zero tile)
-        load(0, 0);
-        store(0, 0);
-        if constexpr (DEPTH == 2) { load(1, 1); load(2, 0); }
-        else load(1, 0);
-        __syncthreads();
-        ldf(fa[0], fb[0], 0, 0);
+        if (first) {
+            load(0, 0);
+            store(0, 0);
+            // (fenced: hipcc's wait-count pass merges the prologue's load order into the loop's; loads reordered HERE make it
+            // wait for the youngest tile inside the loop)
+            VLG_SCHED_FENCE();
+            if constexpr (DEPTH == 2) { load(1, 1); VLG_SCHED_FENCE(); load(2, 0); }
+            else load(1, 0);
+            VLG_SCHED_FENCE();
+            __syncthreads();
+            ldf(ffa[0], ffb[0], 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         for (int kt = 0; kt < nk; kt += 2) { iter(kt, 0); iter(kt + 1, 1); }
-        __syncthreads();
+        __builtin_amdgcn_s_setprio(2);
     };
     // interior blocks (every tile fully inside both operands) take the unguarded instantiation
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) % BK) == 0);
+    const bool interior = (m0 + BM <= g.M) && (n0 + run * BN <= g.N) && (((kend - kbeg) % BK) == 0);
 #ifdef VLG_TIMELINE
     tl_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -369,11 +417,10 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
         // byte offsets from the tile origins are 32-bit in the fast path
         const int64_t ext = kend - kbeg;
         const int64_t span_a = A_KC ? (int64_t)(BM - 1) * g.lda + ext : ext * g.lda + BM;
-        const int64_t span_b = B_KC ? (int64_t)(BN - 1) * g.ldb + ext : ext * g.ldb + BN;
+        const int64_t span_b = B_KC ? (int64_t)(2 * BN - 1) * g.ldb + ext : ext * g.ldb + 2 * BN;   // (+ the next N tile of a run)
         const bool fits = span_a < (1ll << 28) && span_b < (1ll << 28) && (int64_t)(BM - 1) * g.ldc + BN < (1ll << 28);
         fast_tile = interior && fits;
-        if (fast_tile) mainloop_fast();
-        else mainloop(std::true_type{});
+        if (!fast_tile) mainloop(std::true_type{});
     } else {
         if (interior) mainloop(std::false_type{});
         else mainloop(std::true_type{});
@@ -388,7 +435,6 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
         g.clock_probe[2 * bid + 1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 #endif
-    __builtin_amdgcn_s_setprio(2);                   // epilogue: vector work ahead of any younger wave's
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h.
     // 32 lanes of a half write one 128-B row segment per store.
     EO* Cs = static_cast<EO*>(g.C) + (int64_t)split * g.slab_stride;
@@ -437,8 +483,8 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
     };
     // fast epilogue: no address arithmetic on the vector ALU (buffer stores: one loop-constant byte offset per thread, the
     // row in the scalar offset, the 32-column group in the immediate), GELU / dGELU on packed instructions, two rows at a time
-    auto emit_fast = [&]() __attribute__((always_inline)) {
-        const int64_t corner = m0 * g.ldc + n0;
+    auto emit_fast = [&](int n0v) __attribute__((always_inline)) {
+        const int64_t corner = m0 * g.ldc + n0v;
         const __amdgpu_buffer_rsrc_t dc = vlg_rsrc(Cs + corner);
         const __amdgpu_buffer_rsrc_t dxin = vlg_rsrc(gAuxIn ? gAuxIn + corner : gA);
         const __amdgpu_buffer_rsrc_t dxout = vlg_rsrc(gAuxOut ? gAuxOut + corner : Cs + corner);
@@ -453,8 +499,10 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
         float auxb[NAUX][16];
         auto fetch = [&](float (&a)[16], int i, int j) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 16; ++r) {
                 a[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dxin, vc + j * 128, (i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, 0));
+                vlg_epi_pace(r + 1);
+            }
         };
         if constexpr (AUX) {
             if constexpr (AUX_ALL) {
@@ -484,12 +532,14 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
                     for (int q = 0; q < 8; ++q) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv[q].x), dxout, vc + j * 128, soff(2 * q), 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv[q].y), dxout, vc + j * 128, soff(2 * q + 1), 0);
+                        vlg_epi_pace(2 * q + 2);
                     }
                 } else if constexpr ((EPI & VLG_EPI_GELU) != 0) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].x), dxout, vc + j * 128, soff(2 * q), 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].y), dxout, vc + j * 128, soff(2 * q + 1), 0);
+                        vlg_epi_pace(2 * q + 2);
                     }
                     gelu2n<8>(v);
                 }
@@ -513,11 +563,21 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
                 for (int q = 0; q < 8; ++q) {
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].x), dc, vc + j * 128, soff(2 * q), 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].y), dc, vc + j * 128, soff(2 * q + 1), 0);
+                    vlg_epi_pace(2 * q + 2);
                 }
             }
     };
-    if (fast_tile) emit_fast();
-    else if (full) emit(std::false_type{});
+    if (fast_tile) {
+        // the tiles of the run: [main loop, epilogue] per tile; the next tile's bias is fetched ahead of the main loop
+        for (int rt = 0; rt < run; ++rt) {
+            const int n0v = n0 + rt * BN;
+            const bool has_next = rt + 1 < run;
+            mainloop_fast(n0v, rt == 0, has_next);
+            if (has_next) load_bias(n0v + BN);
+            emit_fast(n0v);
+            if (has_next) init_acc();
+        }
+    } else if (full) emit(std::false_type{});
     else emit(std::true_type{});
 #ifdef VLG_TIMELINE
     if (g.clock_probe) {
@@ -568,23 +628,51 @@ static int gemm_bk_override() {
 }
 extern "C" void vlg_debug_set_gemm_bk(int bk) { vlg_gemm_bk_forced = (bk == 16 || bk == 32) ? bk : 0; }
 
+// Consecutive N tiles per block (GemmArgs::run) for a launch that would otherwise take several rounds of blocks: the
+// largest divisor of the N tile count that still leaves one block per slot.  Only where EVERY block takes the fast path
+// (no edge tiles, an even number of K tiles, 32-bit spans): a block that does not computes one tile only.
+static int vlg_gemm_run_forced = -1;
+extern "C" void vlg_debug_set_gemm_run(int run) { vlg_gemm_run_forced = run; }
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
+static int gemm_run(const GemmArgs& g, int slots) {
+    if (BM != 128 || BN != 128 || g.splits != 1) return 1;
+    if (g.M % BM != 0 || g.N % BN != 0 || g.Kc % (2 * BK) != 0) return 1;
+    const int64_t span_a = A_KC ? (int64_t)(BM - 1) * g.lda + g.Kc : g.Kc * g.lda + BM;
+    const int64_t span_b = B_KC ? (int64_t)(2 * BN - 1) * g.ldb + g.Kc : g.Kc * g.ldb + 2 * BN;
+    if (span_a >= (1ll << 28) || span_b >= (1ll << 28) || (int64_t)(BM - 1) * g.ldc + BN >= (1ll << 28)) return 1;
+    if (vlg_gemm_run_forced == 0) return 1;
+    int best = 1;
+    for (int r = 2; r <= g.tiles_n; ++r)
+        if (g.tiles_n % r == 0 && (int64_t)g.tiles_m * (g.tiles_n / r) >= slots) best = r;
+    if (vlg_gemm_run_forced > 0 && g.tiles_n % vlg_gemm_run_forced == 0) best = vlg_gemm_run_forced;
+    return best;
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
 static int launch_gemm(GemmArgs g, hipStream_t s) {
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (g.N + BN - 1) / BN;
-    const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.splits;
-    if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
-    const dim3 grid((unsigned)blocks), block(GEMM_THREADS);
+    g.run = 1;
     g.clock_probe = vlg_gemm_clock_probe;
+    const dim3 block(GEMM_THREADS);
+    constexpr bool CAN_RUN = BM == 128 && BN == 128 && !COLSUM && (EPI & (GEMM_A_GELU | GEMM_B_GELU)) == 0;
     if constexpr (BM == 128 && BN == 128) {
         const int forced = gemm_bk_override();
         const bool heavy_epilogue = (EPI & (VLG_EPI_GELU | VLG_EPI_DGELU)) != 0;
-        if (forced == 16 || (forced != 32 && heavy_epilogue)) {
-            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, A_KC, B_KC, EPI, COLSUM>), grid, block, 0, s, g);
+        int run32 = 1;
+        if constexpr (CAN_RUN) run32 = gemm_run<BM, BN, 32, A_KC, B_KC>(g, 512);
+        // heavy epilogues: three blocks per CU (BK = 16) hide more of the store phase - unless the tiles chain (run > 1)
+        if (forced == 16 || (forced != 32 && heavy_epilogue && run32 == 1)) {
+            const int64_t blocks = (int64_t)g.tiles_m * (g.tiles_n / g.run) * g.splits;
+            if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
+            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, A_KC, B_KC, EPI, COLSUM>), dim3((unsigned)blocks), block, 0, s, g);
             return vlg_last_error();
         }
+        g.run = run32;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM>), grid, block, 0, s, g);
+    const int64_t blocks = (int64_t)g.tiles_m * (g.tiles_n / g.run) * g.splits;
+    if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM>), dim3((unsigned)blocks), block, 0, s, g);
     return vlg_last_error();
 }
 

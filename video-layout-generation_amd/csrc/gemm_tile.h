@@ -16,6 +16,7 @@ struct GemmArgs {
     int64_t Kc;              // contraction extent
     int lda, ldb, ldc;
     int tiles_m, tiles_n, splits;
+    int run;                 // consecutive N tiles one block computes back to back (fp32 fast path; 1 everywhere else)
     int64_t kc_per_split, slab_stride, colsum_off;
     unsigned long long* clock_probe;   // diagnostic only (VLG_GEMM_CLOCK_PROBE): {shader ticks, 100 MHz ticks} per block
 };

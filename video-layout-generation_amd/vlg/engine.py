@@ -204,6 +204,17 @@ class LayoutEngine:
             need.append(lib.vlg_linear_wgrad_slabs_for(M, n, k, self.gemm_flags) * (n * k + n))
         self.slabs = torch.empty(max(need[:2]), **f32)          # partial sums written on the main stream (layer-norm, embedding)
         self.slabs_w = torch.empty(max(need[2:]), **f32)        # weight-gradient partials (written on the side stream in backward)
+        # Option (VLG_ASYNC_REDUCE=1): the slab reductions (27 launches of ~5 us per step) on a stream of their own, beside the
+        # next kernels of backward - nothing but the optimizer (and the gradient all-reduce) reads their results; each
+        # producer family then alternates between two arenas.  MEASURED SLOWER (5.65 -> 5.80 ms per step, one box): the
+        # event hand-offs between the two queues cost more than the 5 us links they take out of the chain.  OFF.
+        self.async_reduce = os.environ.get("VLG_ASYNC_REDUCE", "0") == "1"
+        self.reduce_stream = torch.cuda.Stream(device=self.device)
+        self._arenas = {"w": [self.slabs_w, torch.empty_like(self.slabs_w) if self.async_reduce else self.slabs_w],
+                        "s": [self.slabs, torch.empty_like(self.slabs) if self.async_reduce else self.slabs]}
+        self._arena_turn = {"w": 0, "s": 0}
+        self._arena_busy = {"w": [None, None], "s": [None, None]}
+        self._reduce_pending = None
         # option: backward can run the weight gradients on a second HIP stream, concurrently with the data-gradient chain
         # (see backward).  Measured -1.7 % step time at the metric shape (6.12 -> 6.02 ms): a 512-block launch takes every
         # CU slot, so the other stream's kernel only overlaps its tail.  OFF by default: with two kernels sharing the chip
@@ -218,6 +229,47 @@ class LayoutEngine:
     @staticmethod
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
+
+    def _arena(self, kind: str) -> torch.Tensor:
+        """the slab arena the next producer of this family writes: the current stream first waits for the reduction that
+        last read it"""
+        i = self._arena_turn[kind]
+        e = self._arena_busy[kind][i]
+        if e is not None:
+            torch.cuda.current_stream(self.device).wait_event(e)
+            self._arena_busy[kind][i] = None
+        return self._arenas[kind][i]
+
+    def _reduce(self, kind: str, stride: int, n_slabs: int, dst_off: int, dst_len: int) -> None:
+        """sum the slabs the producer just launched on the current stream wrote into its arena -> grads[dst_off : +dst_len];
+        on the reduction stream (ordered behind the producer by an event) unless VLG_ASYNC_REDUCE=0"""
+        i = self._arena_turn[kind]
+        arena = self._arenas[kind][i]
+        dst = self.grads.data_ptr() + 4 * dst_off
+        if not self.async_reduce:
+            call("vlg_reduce_slabs", ptr(arena), stride, n_slabs, dst, dst_len, self._stream())
+            return
+        cur = torch.cuda.current_stream(self.device)
+        e = torch.cuda.Event()
+        e.record(cur)
+        self.reduce_stream.wait_event(e)
+        with torch.cuda.stream(self.reduce_stream):
+            call("vlg_reduce_slabs", ptr(arena), stride, n_slabs, dst, dst_len, self.reduce_stream.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(self.reduce_stream)
+        self._arena_busy[kind][i] = done
+        self._arena_turn[kind] = i ^ 1
+        self._reduce_pending = done
+
+    def _forget_reduce_events(self) -> None:
+        self._arena_busy = {"w": [None, None], "s": [None, None]}
+        self._reduce_pending = None
+
+    def _join_reduces(self) -> None:
+        """the current stream waits for every slab reduction issued so far (they run in order on one stream)"""
+        if self._reduce_pending is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._reduce_pending)
+            self._reduce_pending = None
 
     def _timed(self, family: str, flops: float, name: str, *args, nbytes: float = 0.0) -> None:
         """Launch through the C ABI; when a timer is attached, bracket the launch with events on
@@ -255,12 +307,12 @@ class LayoutEngine:
         lib = hip.load()
         stride = N * K + N
         n_slabs = lib.vlg_linear_wgrad_slabs_for(M, N, K, self.gemm_flags)
+        arena = self._arena("w")
         s = self._stream()
         self._timed("gemm_wgrad" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_wgrad", ptr(dy), N, ptr(x),
-                    K, ptr(self.slabs_w), stride, self.slabs_w.numel(), M, N, K, self.gemm_flags | self._storage_bits(dy, x) | extra, s,
+                    K, ptr(arena), stride, arena.numel(), M, N, K, self.gemm_flags | self._storage_bits(dy, x) | extra, s,
                     nbytes=dy.element_size() * M * N + x.element_size() * M * K + 4.0 * n_slabs * stride)
-        off = self.layout[wname][0]
-        call("vlg_reduce_slabs", ptr(self.slabs_w), stride, n_slabs, self.grads.data_ptr() + 4 * off, stride, s)
+        self._reduce("w", stride, n_slabs, self.layout[wname][0], stride)
 
     def _ln_fwd(self, x, gname, y, stat, M):
         d = self.cfg.d
@@ -272,12 +324,12 @@ class LayoutEngine:
         d = self.cfg.d
         lib = hip.load()
         n_slabs = lib.vlg_layernorm_bwd_slabs(M)
+        arena = self._arena("s")
         s = self._stream()
         self._timed("ln_bwd", 0.0, "vlg_layernorm_bwd_bf16" if dy.dtype == torch.bfloat16 else "vlg_layernorm_bwd", ptr(dy), ptr(x), ptr(stat[0]),
-                    ptr(stat[1]), ptr(self.p(gname)), ptr(dres), ptr(dx_out), ptr(self.slabs), 2 * d, self.slabs.numel(), M, d, s,
+                    ptr(stat[1]), ptr(self.p(gname)), ptr(dres), ptr(dx_out), ptr(arena), 2 * d, arena.numel(), M, d, s,
                     nbytes=(dy.element_size() + 4.0 + 4.0 + (4.0 if dres is not None else 0.0)) * M * d)
-        off = self.layout[gname][0]
-        call("vlg_reduce_slabs", ptr(self.slabs), 2 * d, n_slabs, self.grads.data_ptr() + 4 * off, 2 * d, s)
+        self._reduce("s", 2 * d, n_slabs, self.layout[gname][0], 2 * d)
 
     def _check_batch(self, batch) -> tuple:
         sc = batch["slot_class"]
@@ -388,6 +440,7 @@ class LayoutEngine:
         self._ln_bwd(self.dh, self.x[L], self.stats[2 * L], "lnf_g", None, self.dx, M)
         if reducer is not None:
             join()
+            self._join_reduces()
             reducer.ready("head")
         if self.overlap_small and not self.overlap_wgrad:
             self._backward_layers_paired(B, T, N, M, reducer)
@@ -418,6 +471,7 @@ class LayoutEngine:
             self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)
             if reducer is not None:
                 join()
+                self._join_reduces()
                 reducer.ready("l%d" % l)
         join()
         self._backward_tail(batch, B, T, N, M, reducer)
@@ -427,9 +481,11 @@ class LayoutEngine:
         lib = hip.load()
         s = self._stream()
         emb_len = self.layout["l0.ln1_g"][0]
-        self._timed("embed_bwd", 0.0, "vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(self.slabs),
-                    emb_len, self.slabs.numel(), B, T, N, d, cfg.vocab, s, nbytes=4.0 * M * d + 24.0 * M)
-        call("vlg_reduce_slabs", ptr(self.slabs), emb_len, lib.vlg_embed_bwd_slabs(), ptr(self.grads), emb_len, s)
+        arena = self._arena("s")
+        self._timed("embed_bwd", 0.0, "vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(arena),
+                    emb_len, arena.numel(), B, T, N, d, cfg.vocab, s, nbytes=4.0 * M * d + 24.0 * M)
+        self._reduce("s", emb_len, lib.vlg_embed_bwd_slabs(), 0, emb_len)
+        self._join_reduces()                       # the gradient buffer is complete for whoever runs next on this stream
         if reducer is not None:
             reducer.ready("embed")
 
@@ -469,6 +525,7 @@ class LayoutEngine:
             beside(lambda: self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M),
                    lambda: self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d))
             if reducer is not None:
+                self._join_reduces()
                 reducer.ready("l%d" % l)
 
     def forward_backward(self, batch: Dict[str, torch.Tensor], reducer=None) -> torch.Tensor:
@@ -545,9 +602,11 @@ class LayoutEngine:
         self.adam_state.copy_(keep[3]); self.step_count = keep[4]
         self._refresh_shadow()
         timer, self.timer = self.timer, None     # events are not capturable work
+        self._forget_reduce_events()             # (recorded by the eager warm-up step: not part of the capture)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
             self.train_step(static)
+        self._forget_reduce_events()             # (recorded inside the capture: meaningless to a later eager step)
         self.timer = timer
         self.params.copy_(keep[0]); self.exp_avg.copy_(keep[1]); self.exp_avg_sq.copy_(keep[2])
         self.adam_state.copy_(keep[3]); self.step_count = keep[4]

@@ -27,6 +27,7 @@ SIGNATURES = {
     "vlg_build_arch": (c_char_p, []),
     "vlg_debug_set_clock_probe": (None, [P]),
     "vlg_debug_set_gemm_bk": (None, [I]),
+    "vlg_debug_set_gemm_run": (None, [I]),
     "vlg_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "vlg_embed_bwd_slabs": (I, []),
     "vlg_embed_bwd": (I, [P, P, P, P, L, L, I, I, I, I, I, P]),
