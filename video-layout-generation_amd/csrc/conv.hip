@@ -36,6 +36,7 @@ struct ConvArgs {
     int cin;                 // channels per tap of the gathered operand (multiple of 32)
     int b_tap_stride;        // dgrad: column offset of one tap inside a weight row
     int shift[9];
+    int wp, sign;            // shift[tap] = sign * ((tap / 3 - 1) * wp + tap % 3 - 1) (0 / 0 with per-tap row tables)
     int tiles_m, tiles_n, splits;
     int64_t kc_per_split, slab_stride, colsum_off;
     int epi;
@@ -67,7 +68,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     static_assert(TM >= 1 && TN >= 1 && TM * 32 * WM == BM && TN * 32 * WN == BN, "tile / wave layout");
     using TA = Tile<BM, A_KC, BK>;
     using TB = Tile<BN, B_KC, BK>;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::FLOATS + TB::FLOATS)];
+    // (+ a 16-byte dump slot per thread where a tile has fewer float4 than the block has threads: the fast path's surplus
+    // threads write there instead of branching around the LDS write)
+    constexpr int DUMP = (TA::F4 % GEMM_THREADS != 0 || TB::F4 % GEMM_THREADS != 0) ? GEMM_THREADS * 4 : 0;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::FLOATS + TB::FLOATS) + DUMP];
     __shared__ float red[GEMM_THREADS / 64];
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * TA::FLOATS;
@@ -278,6 +282,137 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             }
         }
     };
+    // ---- fast path (forward / data gradient of a stride-1 convolution with one slope for every staged channel): the main
+    // loop of gemm.hip's fast path - NO vector-ALU instruction for addresses.  v_mfma_f32_32x32x2_f32 and the vector ALU of
+    // a SIMD execute serially (tools/micro/mfma_f32_valu_share.hip): the general loop above spends 60-140 vector instructions
+    // per K tile (64-bit pointers, LDS addresses, a three-instruction PReLU with per-channel slope selects) against 16-64
+    // MFMAs, i.e. 20-45 % of the matrix pipe's time.  Here: buffer loads (per-thread byte offset constant, the tap's row shift,
+    // the channel block and the float4 number in the scalar offset; the descriptor ends at the last row any tap of a valid
+    // output row can reach, so the rows a partial row tile reads beyond it come back as zeros), two iterations unrolled (LDS
+    // addresses are immediates), the tap / channel counters on the scalar unit, PReLU as a packed multiply + one med3.
+    bool fast = false;
+    if constexpr (MODE != CONV_WGRAD && BM >= 64) {
+        const int pad = g.wp + 1;
+        const int64_t a_bytes = (g.M + 2 * (int64_t)pad) * g.lda * 4;
+        const int64_t b_bytes = (MODE == CONV_FWD ? (int64_t)g.N : (int64_t)g.cin) * g.ldb * 4;
+        fast = g.rowtab == nullptr && g.wp > 0 && (g.N % BN) == 0 && a_bytes + (int64_t)BM * g.lda * 4 < (1ll << 31) && b_bytes < (1ll << 31) &&
+               (MODE != CONV_FWD || g.act_ch >= g.cin) && ((kend - kbeg) % BK) == 0;
+        if (fast) {
+            const int lda = g.lda, ldb = g.ldb;
+            const __amdgpu_buffer_rsrc_t da = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A - (int64_t)pad * lda), 0, (int)a_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t db = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (int)b_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t dz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, 0, 0x00020000);   // empty: zeros
+            const int va = TA::voff_bytes(lda, tid), vb = TB::voff_bytes(ldb, tid);
+            const int a_is = TA::ISTEP * lda * 4, b_is = TB::ISTEP * ldb * 4;
+            float* const aw = smem + TA::soff(tid);
+            // threads beyond a short B tile (TB::F4 < threads; NV = 1 then) write their float4 to the dump area: for buffer 1 the
+            // store adds TB::FLOATS to the base, so their base is the dump slot minus nothing for buffer 0 ... both land inside
+            // [tiles end - TB::FLOATS, tiles end + DUMP) only if the base is chosen per buffer: two bases
+            const bool surplus = TB::F4 % GEMM_THREADS != 0 && tid >= TB::F4;
+            float* const bw0 = surplus ? smem + 2 * (TA::FLOATS + TB::FLOATS) + 4 * tid : smem + 2 * TA::FLOATS + TB::soff(tid);
+            float* const bw1 = surplus ? bw0 : bw0 + TB::FLOATS;
+            const float* ar[TM];
+            const float* br[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ar[i] = smem + TA::roff((wm * TM + i) * 32 + l31, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) br[j] = smem + 2 * TA::FLOATS + TB::roff((wn * TN + j) * 32 + l31, h);
+            v4f xa[TA::NV], xb[TB::NV];
+            // scalar K-tile cursor of the NEXT load: tap = 3 * ky + kx, channel block ci
+            int l_t = 0, l_ci = (int)(kbeg % g.cin), l_tap = (int)(kbeg / g.cin);
+            int l_ky = l_tap / 3, l_kx = l_tap - 3 * l_ky;
+            // (block-uniform by construction; said explicitly, or hipcc wraps every buffer load in a waterfall loop)
+            const int m0i = __builtin_amdgcn_readfirstlane((int)m0), n0u = __builtin_amdgcn_readfirstlane(n0);
+            l_ci = __builtin_amdgcn_readfirstlane(l_ci); l_tap = __builtin_amdgcn_readfirstlane(l_tap);
+            l_ky = __builtin_amdgcn_readfirstlane(l_ky); l_kx = __builtin_amdgcn_readfirstlane(l_kx);
+            const int kbeg_i = __builtin_amdgcn_readfirstlane((int)kbeg);
+            auto load = [&]() __attribute__((always_inline)) {
+                const bool in = l_t < nk;
+                const int shift = g.sign * ((l_ky - 1) * g.wp + l_kx - 1);
+                const int oa = ((m0i + shift + pad) * lda + l_ci) * 4;
+                const int ob = MODE == CONV_FWD ? (n0u * ldb + kbeg_i + l_t * BK) * 4 : (l_ci * ldb + l_tap * g.b_tap_stride + n0u) * 4;
+                const __amdgpu_buffer_rsrc_t ua = in ? da : dz, ub = in ? db : dz;
+#pragma unroll
+                for (int i = 0; i < TA::NV; ++i) xa[i] = __builtin_amdgcn_raw_buffer_load_b128(ua, va, oa + i * a_is, 0);
+#pragma unroll
+                for (int i = 0; i < TB::NV; ++i) xb[i] = __builtin_amdgcn_raw_buffer_load_b128(ub, vb, ob + i * b_is, 0);
+                ++l_t;                                          // (selects, not branches: the iteration stays one basic block)
+                const bool wrap_c = l_ci + BK >= g.cin, wrap_x = wrap_c && l_kx == 2;
+                l_ci = wrap_c ? 0 : l_ci + BK;
+                l_tap += wrap_c ? 1 : 0;
+                l_kx = wrap_x ? 0 : l_kx + (wrap_c ? 1 : 0);
+                l_ky += wrap_x ? 1 : 0;
+            };
+            // PReLU of the staged operand: v > 0 ? v : a v  ==  a <= 1 ? max(v, a v) : min(v, a v)  ==  med3(v, a v, +-inf), bit for
+            // bit what the general path computes (one rounding, in a v); slope 1 (no activation) skips it
+            const bool act_on = MODE == CONV_FWD && slope != 1.0f;
+            const float sel = slope <= 1.0f ? __builtin_inff() : -__builtin_inff();
+            const v2f slope2 = v2(slope);
+            auto store = [&](int c, auto act_tag) __attribute__((always_inline)) {
+                if constexpr (decltype(act_tag)::value) {
+#pragma unroll
+                    for (int i = 0; i < TA::NV; ++i) {
+                        // (as asm: left to itself hipcc multiplies the four lanes one by one)
+                        v2f lo, hi;
+                        const v2f p0 = __builtin_shufflevector(xa[i], xa[i], 0, 1), p1 = __builtin_shufflevector(xa[i], xa[i], 2, 3);
+                        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "v"(p0), "v"(slope2));
+                        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(hi) : "v"(p1), "v"(slope2));
+                        xa[i] = v4f{__builtin_amdgcn_fmed3f(xa[i].x, lo.x, sel), __builtin_amdgcn_fmed3f(xa[i].y, lo.y, sel),
+                                    __builtin_amdgcn_fmed3f(xa[i].z, hi.x, sel), __builtin_amdgcn_fmed3f(xa[i].w, hi.y, sel)};
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TA::NV; ++i) *reinterpret_cast<v4f*>(aw + c * TA::FLOATS + i * TA::SSTEP) = xa[i];
+#pragma unroll
+                for (int i = 0; i < TB::NV; ++i) *reinterpret_cast<v4f*>((c ? bw1 : bw0) + i * TB::SSTEP) = xb[i];
+            };
+            auto ldf = [&](float (&a)[TM][4], float (&b)[TN][4], int c, int sch) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) TA::frag_at(a[i], ar[i] + c * TA::FLOATS, 0, sch);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) TB::frag_at(b[j], br[j] + c * TB::FLOATS, 0, sch);
+            };
+            auto fiter = [&](int cur, auto act_tag) __attribute__((always_inline)) {
+#pragma unroll
+                for (int sch = 0; sch < NCH; ++sch) {
+                    if (sch + 1 < NCH) ldf(fa[(sch + 1) & 1], fb[(sch + 1) & 1], cur, sch + 1);
+                    if (sch == NCH - 1) {
+                        __syncthreads();
+                        ldf(fa[0], fb[0], cur ^ 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (sch == SS) { store(cur ^ 1, act_tag); load(); }
+                    mma(fa[sch & 1], fb[sch & 1]);
+                    if (sch == SS) {
+                        constexpr int N_MFMA = 4 * TM * TN, N_ST = TA::NV + TB::NV, N_LD = TA::NV + TB::NV;
+                        constexpr int PER = (N_ST + N_LD + N_MFMA - 1) / N_MFMA;
+#pragma unroll
+                        for (int i = 0; i < N_MFMA; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                            for (int q = 0; q < PER; ++q) {
+                                const int slot = i * PER + q;
+                                if (slot < N_ST) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                                else if (slot < N_ST + N_LD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                            }
+                        }
+                    }
+                }
+            };
+            load();
+            if (act_on) store(0, std::true_type{});
+            else store(0, std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            load();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            ldf(fa[0], fb[0], 0, 0);
+            // (an odd nk runs one iteration on a zero tile; one copy of the loop with, one without the activation)
+            if (act_on) { for (int kt = 0; kt < nk; kt += 2) { fiter(0, std::true_type{}); fiter(1, std::true_type{}); } }
+            else { for (int kt = 0; kt < nk; kt += 2) { fiter(0, std::false_type{}); fiter(1, std::false_type{}); } }
+        }
+    }
+    if (!fast) {
     if (nk > 0) { gload(kbeg); sstore(0); }
     if (nk > 1) gload(kbeg + BK);
     __syncthreads();
@@ -287,6 +422,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
         for (; kt + 2 < nk; ++kt) iter(kt, std::true_type{}, std::true_type{}, std::true_type{});
         if (kt + 1 < nk) { iter(kt, std::true_type{}, std::false_type{}, std::true_type{}); ++kt; }
         if (kt < nk) iter(kt, std::false_type{}, std::false_type{}, std::false_type{});
+    }
     }
     __syncthreads();
 
@@ -350,6 +486,7 @@ static int launch_conv(ConvArgs g, hipStream_t s) {
 static void fill_shifts(ConvArgs& g, int wp, int sign) {
     for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx) g.shift[ky * 3 + kx] = sign * ((ky - 1) * wp + (kx - 1));
+    g.wp = wp; g.sign = sign;
 }
 
 // development switch: VLG_CONV_NARROW_BK=16|32 selects the K-tile depth of the 32-channel tiles

@@ -47,14 +47,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t vlg_rsrc(const void* p, int by
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
-// Epilogue pacing.  The CU's vector-memory pipeline is one FIFO for all its waves and takes ~5 cycles per 128-B line
-// (tools/micro/mfma_f32_valu_share.hip mem): a 64 KB epilogue burst (512 lines, 1024 with an auxiliary operand) holds it for
-// 1-2 us, and the co-resident block - whose waves issue in order - stalls at the ISSUE of its next tile's loads with the
-// matrix pipe idle (per-CU timelines: +1.3 us per block behind a plain store epilogue, +3.4 us behind loads + stores; a
-// deeper tile prefetch does not help, the wave never gets to issue it).  So the epilogue sleeps between small groups of
-// memory instructions: it lasts longer, but the FIFO stays short and the other block's loads slip in.
+// Epilogue pacing (compile-time option, OFF: measured neutral, tools/ab/gemm_ab.py).  The CU's vector-memory pipeline is one
+// FIFO for all its waves and takes ~5 cycles per 128-B line (tools/micro/mfma_f32_valu_share.hip mem), so a 64 KB epilogue
+// burst holds it for 1-2 us; sleeping between small groups of the epilogue's memory instructions (-DVLG_EPI_PACE=1) keeps the
+// FIFO short for the co-resident block's tile loads - but that block's waves are not waiting on the FIFO: what they wait
+// for is the vector ALU (oldest wave first), so nothing is gained.
 #ifndef VLG_EPI_PACE
-#define VLG_EPI_PACE 1          /* s_sleep argument (x 64 cycles) behind every VLG_EPI_PACE_EVERY memory instructions; 0 = off */
+#define VLG_EPI_PACE 0          /* s_sleep argument (x 64 cycles) behind every VLG_EPI_PACE_EVERY memory instructions; 0 = off */
 #endif
 #ifndef VLG_EPI_PACE_EVERY
 #define VLG_EPI_PACE_EVERY 2
