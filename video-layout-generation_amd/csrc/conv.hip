@@ -412,6 +412,128 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             else { for (int kt = 0; kt < nk; kt += 2) { fiter(0, std::false_type{}); fiter(1, std::false_type{}); } }
         }
     }
+    // ---- weight gradient, fast path (stride 1, one slope for every gathered channel): the same loop; A = dOut rows
+    // [k][cout], B = gathered activation rows [k][(tap, channel)] - a thread's column, hence its tap's row shift, is fixed,
+    // so its byte offset is a constant and the K advance is scalar.  The bias gradient is summed from the staging registers
+    // (as gemm.hip does) instead of re-reading the LDS tile by a few threads behind a divergent branch.
+    v2f wcol[TA::NV][2];
+#pragma unroll
+    for (int i = 0; i < TA::NV; ++i) { wcol[i][0] = v2(0.f); wcol[i][1] = v2(0.f); }
+    if constexpr (MODE == CONV_WGRAD) {
+        const int pad = g.wp + 1;
+        const int64_t a_bytes = g.Kc * (int64_t)g.lda * 4, b_bytes = (g.Kc + 2 * (int64_t)pad) * g.ldb * 4;
+        fast = g.rowtab == nullptr && g.wp > 0 && g.act_ch >= g.cin && a_bytes < (1ll << 31) && b_bytes < (1ll << 31) &&
+               (int64_t)g.M * g.ldc * 4 < (1ll << 31) && (kbeg % BK) == 0;
+        if (fast) {
+            const int lda = g.lda, ldb = g.ldb;
+            const __amdgpu_buffer_rsrc_t da = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)a_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t db = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B - (int64_t)pad * ldb), 0, (int)b_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t dz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, 0, 0x00020000);
+            const int m0u = __builtin_amdgcn_readfirstlane((int)m0);
+            int va[TA::NV];
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) {
+                const int idx = tid + GEMM_THREADS * i;
+                va[i] = ((idx / (BM / 4)) * lda + m0u + ((idx % (BM / 4)) << 2)) * 4;
+            }
+            int col = n0 + ((tid % (BN / 4)) << 2);
+            if (col > g.N - 4) col = g.N - 4;                  // columns past N are computed but never stored
+            const int tapc = col / g.cin;
+            const int shc = g.sign * ((tapc / 3 - 1) * g.wp + tapc % 3 - 1);
+            const int vb = ((tid / (BN / 4) + shc + pad) * ldb + (col - tapc * g.cin)) * 4;
+            const int b_is = TB::ISTEP * ldb * 4;
+            float* const aw = smem + TA::soff(tid);
+            float* const bw = smem + 2 * TA::FLOATS + TB::soff(tid);
+            const float* ar[TM];
+            const float* br[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ar[i] = smem + TA::roff((wm * TM + i) * 32 + l31, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) br[j] = smem + 2 * TA::FLOATS + TB::roff((wn * TN + j) * 32 + l31, h);
+            v4f xa[TA::NV], xb[TB::NV];
+            const int kbeg_i = __builtin_amdgcn_readfirstlane((int)kbeg);
+            int l_t = 0;
+            auto load = [&]() __attribute__((always_inline)) {
+                const bool in = l_t < nk;
+                const int k0 = kbeg_i + l_t * BK;
+                const __amdgpu_buffer_rsrc_t ua = in ? da : dz, ub = in ? db : dz;
+#pragma unroll
+                for (int i = 0; i < TA::NV; ++i) xa[i] = __builtin_amdgcn_raw_buffer_load_b128(ua, va[i], k0 * lda * 4, 0);
+#pragma unroll
+                for (int i = 0; i < TB::NV; ++i) xb[i] = __builtin_amdgcn_raw_buffer_load_b128(ub, vb, k0 * ldb * 4 + i * b_is, 0);
+                ++l_t;
+            };
+            const bool act_on = slope != 1.0f;
+            const float sel = slope <= 1.0f ? __builtin_inff() : -__builtin_inff();
+            const v2f slope2 = v2(slope);
+            auto store = [&](int c, auto act_tag) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < TA::NV; ++i) {
+                    const v2f lo = __builtin_shufflevector(xa[i], xa[i], 0, 1), hi = __builtin_shufflevector(xa[i], xa[i], 2, 3);
+                    asm("v_pk_add_f32 %0, %0, %1" : "+v"(wcol[i][0]) : "v"(lo));
+                    asm("v_pk_add_f32 %0, %0, %1" : "+v"(wcol[i][1]) : "v"(hi));
+                }
+                if constexpr (decltype(act_tag)::value) {
+#pragma unroll
+                    for (int i = 0; i < TB::NV; ++i) {
+                        v2f lo, hi;
+                        const v2f p0 = __builtin_shufflevector(xb[i], xb[i], 0, 1), p1 = __builtin_shufflevector(xb[i], xb[i], 2, 3);
+                        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "v"(p0), "v"(slope2));
+                        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(hi) : "v"(p1), "v"(slope2));
+                        xb[i] = v4f{__builtin_amdgcn_fmed3f(xb[i].x, lo.x, sel), __builtin_amdgcn_fmed3f(xb[i].y, lo.y, sel),
+                                    __builtin_amdgcn_fmed3f(xb[i].z, hi.x, sel), __builtin_amdgcn_fmed3f(xb[i].w, hi.y, sel)};
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TA::NV; ++i) *reinterpret_cast<v4f*>(aw + c * TA::FLOATS + i * TA::SSTEP) = xa[i];
+#pragma unroll
+                for (int i = 0; i < TB::NV; ++i) *reinterpret_cast<v4f*>(bw + c * TB::FLOATS + i * TB::SSTEP) = xb[i];
+            };
+            auto ldf = [&](float (&a)[TM][4], float (&b)[TN][4], int c, int sch) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) TA::frag_at(a[i], ar[i] + c * TA::FLOATS, 0, sch);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) TB::frag_at(b[j], br[j] + c * TB::FLOATS, 0, sch);
+            };
+            auto fiter = [&](int cur, auto act_tag) __attribute__((always_inline)) {
+#pragma unroll
+                for (int sch = 0; sch < NCH; ++sch) {
+                    if (sch + 1 < NCH) ldf(fa[(sch + 1) & 1], fb[(sch + 1) & 1], cur, sch + 1);
+                    if (sch == NCH - 1) {
+                        __syncthreads();
+                        ldf(fa[0], fb[0], cur ^ 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (sch == SS) { store(cur ^ 1, act_tag); load(); }
+                    mma(fa[sch & 1], fb[sch & 1]);
+                    if (sch == SS) {
+                        constexpr int N_MFMA = 4 * TM * TN, N_ST = TA::NV + TB::NV, N_LD = TA::NV + TB::NV;
+                        constexpr int PER = (N_ST + N_LD + N_MFMA - 1) / N_MFMA;
+#pragma unroll
+                        for (int i = 0; i < N_MFMA; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                            for (int q = 0; q < PER; ++q) {
+                                const int slot = i * PER + q;
+                                if (slot < N_ST) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                                else if (slot < N_ST + N_LD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                            }
+                        }
+                    }
+                }
+            };
+            load();
+            if (act_on) store(0, std::true_type{});
+            else store(0, std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            load();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            ldf(fa[0], fb[0], 0, 0);
+            if (act_on) { for (int kt = 0; kt < nk; kt += 2) { fiter(0, std::true_type{}); fiter(1, std::true_type{}); } }
+            else { for (int kt = 0; kt < nk; kt += 2) { fiter(0, std::false_type{}); fiter(1, std::false_type{}); } }
+        }
+    }
     if (!fast) {
     if (nk > 0) { gload(kbeg); sstore(0); }
     if (nk > 1) gload(kbeg + BK);
@@ -431,6 +553,92 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     const int64_t row0 = m0 + wm * TM * 32 + 4 * h;
     const int col0 = n0 + wn * TN * 32 + l31;
     float da = 0.f;
+    // fast epilogue (with the fast main loop; every column of the tile is stored, the data gradient cuts no constant
+    // channels): buffer loads / stores - the descriptors end with row M, so the rows of a partial row tile beyond it are
+    // dropped by the hardware instead of by a compare per element - one byte offset per thread, the row in the scalar
+    // offset; two rows at a time on packed instructions.  The general epilogue below spends ~15 vector instructions per
+    // element (64-bit offsets, bounds, flag tests): a quarter of a 32-channel tile's matrix time.
+    bool fast_epi = false;
+    if constexpr (MODE != CONV_WGRAD) fast_epi = fast && (MODE != CONV_DGRAD || g.act_ch >= g.N) && g.M * (int64_t)g.ldc * 4 < (1ll << 31);
+    if constexpr (MODE != CONV_WGRAD) {
+      if (fast_epi) {
+        const int m0u = __builtin_amdgcn_readfirstlane((int)m0), n0u = __builtin_amdgcn_readfirstlane(n0);
+        const int cbytes = (int)(g.M * (int64_t)g.ldc * 4);
+        const __amdgpu_buffer_rsrc_t dC = __builtin_amdgcn_make_buffer_rsrc(Cs, 0, cbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t dX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux_in ? g.aux_in : g.A), 0, g.aux_in ? cbytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t dMk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.rowmask ? g.rowmask : g.A), 0, g.rowmask ? (int)(g.M * 4) : 0, 0x00020000);
+        const int vc = ((wm * TM * 32 + 4 * h) * g.ldc + wn * TN * 32 + l31) * 4;
+        const int vm = (wm * TM * 32 + 4 * h) * 4;
+        const bool e_resid = (g.epi & VLG_CEPI_RESID) != 0, e_prelu = (g.epi & VLG_CEPI_PRELU) != 0, e_dprelu = (g.epi & VLG_CEPI_DPRELU) != 0,
+                   e_accum = (g.epi & VLG_CEPI_ACCUM) != 0, e_mask = g.rowmask != nullptr;
+        const float sel = slope <= 1.0f ? __builtin_inff() : -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            v2f mk[8];                                            // the row mask of this 32-row group (shared by its column tiles)
+            if (e_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    mk[r >> 1][r & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dMk, vm, (m0u + i * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const auto so = [&](int r) { return ((m0u + i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + n0u) * 4; };
+                v2f x[8], o[8], v[8];
+                if (e_resid || e_dprelu) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[r >> 1][r & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dX, vc + j * 128, so(r), 0));
+                }
+                if (e_accum) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r >> 1][r & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dC, vc + j * 128, so(r), 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = v2f{acc[i][j][2 * q], acc[i][j][2 * q + 1]};
+                if constexpr (MODE == CONV_FWD) {
+                    if (g.bias != nullptr) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += v2(bv[j]);
+                    }
+                    if (e_resid) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += x[q];
+                    }
+                    if (e_prelu) {                              // v > 0 ? v : slope v  ==  med3(v, slope v, +-inf)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const v2f t = v[q] * v2(slope);
+                            v[q] = v2f{__builtin_amdgcn_fmed3f(v[q].x, t.x, sel), __builtin_amdgcn_fmed3f(v[q].y, t.y, sel)};
+                        }
+                    }
+                }
+                if (e_mask) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= mk[q];
+                }
+                if constexpr (MODE == CONV_DGRAD) {
+                    if (e_dprelu) {                             // slope gradient += v x [x <= 0];  v *= x > 0 ? 1 : slope
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            da = fmaf(v[q].x, __builtin_amdgcn_fmed3f(x[q].x, 0.f, -__builtin_inff()), da);
+                            da = fmaf(v[q].y, __builtin_amdgcn_fmed3f(x[q].y, 0.f, -__builtin_inff()), da);
+                            v[q] *= v2f{x[q].x > 0.f ? 1.0f : slope, x[q].y > 0.f ? 1.0f : slope};
+                        }
+                    }
+                    if (e_accum) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += o[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].x), dC, vc + j * 128, so(2 * q), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].y), dC, vc + j * 128, so(2 * q + 1), 0);
+                }
+            }
+        }
+      }
+    }
+    if (!fast_epi)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -463,7 +671,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             }
         }
     if constexpr (MODE == CONV_WGRAD) {
-        if (tn == 0 && tid < BM && m0 + tid < g.M) Cs[g.colsum_off + m0 + tid] = colacc;
+        if (fast) {
+            // bias gradient: (thread, float4 i) summed columns 4 * (idx % (BM / 4)) .. + 3 over its K rows; 32 such partials per column
+            if (tn == 0) {
+#pragma unroll
+                for (int i = 0; i < TA::NV; ++i) st4(smem + 4 * (tid + GEMM_THREADS * i), make_float4(wcol[i][0].x, wcol[i][0].y, wcol[i][1].x, wcol[i][1].y));
+                __syncthreads();
+                if (tid < BM && m0 + tid < g.M) {
+                    float sacc = 0.f;
+#pragma unroll 8
+                    for (int e = 0; e < GEMM_THREADS * TA::NV / (BM / 4); ++e) sacc += smem[4 * ((tid >> 2) + e * (BM / 4)) + (tid & 3)];
+                    Cs[g.colsum_off + m0 + tid] = sacc;
+                }
+            }
+        } else if (tn == 0 && tid < BM && m0 + tid < g.M) Cs[g.colsum_off + m0 + tid] = colacc;
     }
     if constexpr (MODE == CONV_DGRAD) {
         if (g.da_slab != nullptr) {                             // slope gradient: one partial per block
