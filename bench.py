@@ -355,6 +355,21 @@ def main():
                     line[key]["families"] = {k: {"avg_us": round(1e3 * v["avg_ms"], 2), "gbs": round(v["bytes_per_launch"] / (v["avg_ms"] * 1e-3) / 1e9, 1)}
                                              for k, v in fam.items()}
                 del e2
+            # informational: the same native fp32 step with the weight gradients on a second HIP stream (LayoutEngine option
+            # VLG_OVERLAP_WGRAD=1): launch boundaries and the bandwidth-bound kernels of the chain then overlap with them.  NOT
+            # the default and not `value`: two kernels sharing the chip make a kernel's own duration (the roofline object)
+            # meaningless
+            os.environ["VLG_OVERLAP_WGRAD"] = "1"
+            e3 = LayoutEngine(cfg, dev, seed=SEED)
+            os.environ.pop("VLG_OVERLAP_WGRAD")
+            for _ in range(3):
+                e3.train_step(batch)
+            dt = timed_steps(lambda: e3.train_step(batch), 10)
+            line["two_stream_backward"] = {"value": round(cfg.B / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt, 4),
+                                           "note": "native fp32, weight gradients (+ slab reductions) on a second stream beside the "
+                                                   "data-gradient chain; same results bit for bit (tests/test_hip_step.py)",
+                                           "final_loss": round(float(e3.loss_out[0]), 5)}
+            del e3
             # the reference's batch semantics are GLOBAL (src/main.py:105-106, src/trainer.py:148: per-GPU = 32 // gpus):
             # the 8-GPU share of the metric batch is 4 clips per GPU - measurable on one GPU, informational
             c4 = LayoutConfig(B=max(cfg.B // 8, 1), T=cfg.T, N=cfg.N, d=cfg.d, n_layers=cfg.n_layers)

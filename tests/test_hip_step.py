@@ -266,3 +266,25 @@ def test_captured_step_replays_bitwise(dev, precision):
     assert_close(host.params, eager.params, rtol=1e-5, atol=1e-7, what="params, host vs device step counter")
     if precision == "bf16":
         assert torch.equal(graphed.params_bf16, graphed.params.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("option", ["VLG_OVERLAP_WGRAD", "VLG_ASYNC_REDUCE", "VLG_OVERLAP_SMALL"])
+def test_stream_options_do_not_change_results(dev, option, monkeypatch):
+    """The engine's multi-stream options (weight gradients on a second stream, slab reductions on a stream of their own,
+    bandwidth-bound kernels beside the weight gradients) only reorder launches across streams: parameters and losses after
+    three steps must be bit for bit those of the single-stream step."""
+    from vlg.engine import LayoutEngine
+    from vlg.spec import LayoutConfig
+    cfg = LayoutConfig(B=4, T=16, N=24, d=256, n_layers=2)
+    batches = [to_dev(O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=70 + i), dev) for i in range(3)]
+    plain = LayoutEngine(cfg, dev)
+    monkeypatch.setenv(option, "1")
+    opt = LayoutEngine(cfg, dev)
+    monkeypatch.delenv(option)
+    assert {"VLG_OVERLAP_WGRAD": opt.overlap_wgrad, "VLG_ASYNC_REDUCE": opt.async_reduce, "VLG_OVERLAP_SMALL": opt.overlap_small}[option]
+    for b in batches:
+        lp = plain.train_step(b).clone()
+        lo = opt.train_step(b).clone()
+        assert torch.equal(lp, lo), (lp, lo)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.params, opt.params) and torch.equal(plain.exp_avg_sq, opt.exp_avg_sq)
