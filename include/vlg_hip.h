@@ -46,7 +46,8 @@ void vlg_debug_set_clock_probe(unsigned long long* buf);
 /* diagnostic only (tools/ab/gemm_ab.py): force the contraction depth per LDS tile of the 128x128 fp32 GEMM kernels
  * (16 | 32; 0 = the library's own choice per epilogue; the VLG_GEMM_BK environment variable sets the initial value) */
 void vlg_debug_set_gemm_bk(int bk);
-/* diagnostic only: consecutive N tiles per block of the chained fp32 GEMM path (0 = never chain, -1 = the library's choice) */
+/* diagnostic only: consecutive N tiles per block of the chained fp32 GEMM path (0 = never chain, -1 = the library's choice;
+ * bit 16: chained launches as ping-pong pairs of four-wave groups - measured slower, see csrc/gemm.hip) */
 void vlg_debug_set_gemm_run(int run);
 
 /* ------------------------------------------------------------------ embedding

@@ -202,6 +202,39 @@ def test_linear_gelu_grad_saved_and_mul(H, dev, M, N, K):
     assert lib.vlg_linear_dgrad(dyd.data_ptr(), K2, w2d.data_ptr(), N, du.data_ptr(), N, 0, M, K2, N, H.EPI_MUL, stream()) == 1001
 
 
+@pytest.mark.parametrize("pingpong", [True, False])
+def test_linear_chained_tiles(H, dev, pingpong):
+    """Multi-round launches: a block computes a run of N tiles back to back (the K loop continues into the next tile), as two
+    four-wave groups per workgroup that take turns (diagnostic option) or as independent 256-thread workgroups (default).  1024 tiles here ->
+    runs of two; forward with bias, forward with GELU + saved derivative, data gradient with the multiply epilogue."""
+    M, N, K = 8192, 2048, 128
+    lib = H.load()
+    lib.vlg_debug_set_gemm_run(0x1ffff if pingpong else -1)
+    try:
+        torch.manual_seed(21)
+        a, w, b = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+        pre = F.linear(a.double(), w.double(), b.double())
+        ad, wd, bd = a.to(dev), w.to(dev), b.to(dev)
+        c = torch.full((M, N), float("nan"), device=dev)
+        H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, 0, M, N, K, H.EPI_BIAS, stream())
+        assert_close(c, pre.float(), rtol=1e-4, atol=1e-5, what="chained fwd bias")
+        dsave = torch.full((M, N), float("nan"), device=dev)
+        H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, dsave.data_ptr(), M, N, K,
+               H.EPI_BIAS | H.EPI_GELU | H.EPI_GELU_GRAD, stream())
+        uu = pre.clone().requires_grad_(True)
+        F.gelu(uu).sum().backward()
+        assert_close(c, F.gelu(pre).float(), what="chained gelu")
+        assert_close(dsave, uu.grad.float(), rtol=1e-4, atol=1e-5, what="chained saved gelu'")
+        # data gradient into a wide output: dX[M, N] = dY[M, K] . W2[K, N], times the saved derivative
+        dy, w2 = torch.randn(M, K), torch.randn(K, N) / math.sqrt(K)
+        dyd, w2d = dy.to(dev), w2.to(dev)
+        dx = torch.full((M, N), float("nan"), device=dev)
+        H.call("vlg_linear_dgrad", dyd.data_ptr(), K, w2d.data_ptr(), N, dx.data_ptr(), N, dsave.data_ptr(), M, K, N, H.EPI_MUL, stream())
+        assert_close(dx, ((dy.double() @ w2.double()) * uu.grad).float(), rtol=1e-4, atol=1e-5, what="chained dgrad * saved")
+    finally:
+        lib.vlg_debug_set_gemm_run(-1)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 1024), (300, 128, 512), (1000, 256, 96)])
 def test_linear_gelu_on_load(H, dev, M, N, K):
     """VLG_EPI_ACT_GELU: the activation operand holds PRE-activations u and gelu(u) is formed while the tile is staged -

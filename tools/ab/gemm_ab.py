@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """A/B of fp32 GEMM builds in ONE process, interleaved rounds (guide rule 24: separate invocations differ by several per
-cent on one box).  Every argument is `tag=path/to/libvlg.so[:BK]` (BK = forced contraction depth 16 | 32 through
-vlg_debug_set_gemm_bk when the build exports it); `cur` = the in-tree build.
+cent on one box).  Every argument is `tag=path/to/libvlg.so[:BK[:RUN]]` (BK = forced contraction depth 16 | 32 | 0 through
+vlg_debug_set_gemm_bk, RUN = argument of vlg_debug_set_gemm_run, e.g. 0x1ffff = chained tiles as ping-pong pairs, 0 = no
+chaining; when the build exports them); `cur` = the in-tree build.
     python tools/ab/gemm_ab.py base=tools/ab/libvlg_base.so cur [--only gelu] [--rounds 7]
 """
 import ctypes
@@ -31,12 +32,13 @@ def main():
     for a in args:
         tag, _, rest = a.partition("=")
         path, _, bk = rest.partition(":")
+        bk, _, run = bk.partition(":")
         path = path or os.path.join(ROOT, "video-layout-generation_amd", "libvlg_hip.so")
         lib = ctypes.CDLL(os.path.abspath(path))
         for n, sig in SIG.items():
             getattr(lib, n).argtypes = sig
             getattr(lib, n).restype = I
-        libs.append((tag + (":" + bk if bk else ""), lib, int(bk) if bk else 0))
+        libs.append((tag + (":" + bk if bk else ""), lib, int(bk) if bk else 0, int(run, 0) if run else -1))
     dev = torch.device("cuda:0")
     S = torch.cuda.current_stream().cuda_stream
     M, d = 32768, 256
@@ -65,7 +67,7 @@ def main():
     for nm, n, k, dy, xx in (("qkv", 3 * d, d, x_3d, x_d), ("proj", d, d, y_d, x_d), ("ff1", ff, d, x_ff, x_d), ("ff2", d, ff, x_d, x_ff)):
         cases.append(("wgrad " + nm, fl(n, k), lambda l, n=n, k=k, dy=dy, xx=xx: l.vlg_linear_wgrad(p(dy), n, p(xx), k, p(slabs), n * k + n, slabs.numel(), M, n, k, 0, S)))
     cases = [c for c in cases if only in c[0]]
-    for tag, lib, bk in libs:                      # every build must accept every case (and size its slabs within the buffer)
+    for tag, lib, bk, run in libs:                      # every build must accept every case (and size its slabs within the buffer)
         for nm, n, k in (("qkv", 3 * d, d), ("proj", d, d), ("ff1", ff, d), ("ff2", d, ff)):
             assert lib.vlg_linear_wgrad_slabs_for(M, n, k, 0) * (n * k + n) <= slabs.numel()
     times = {(c[0], t[0]): [] for c in cases for t in libs}
@@ -73,9 +75,11 @@ def main():
         cases[0][2](libs[0][1])
     for rnd in range(rounds + 1):
         for name, work, fn in cases:
-            for tag, lib, bk in libs:
+            for tag, lib, bk, run in libs:
                 if hasattr(lib, "vlg_debug_set_gemm_bk"):
                     lib.vlg_debug_set_gemm_bk(bk)
+                if hasattr(lib, "vlg_debug_set_gemm_run"):
+                    lib.vlg_debug_set_gemm_run(run)
                 if fn(lib) != 0:                    # this build does not know the epilogue
                     continue
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -90,7 +94,7 @@ def main():
     tot = [0.0] * len(libs)
     for name, work, fn in cases:
         row = "%-18s" % name
-        for i, (tag, lib, bk) in enumerate(libs):
+        for i, (tag, lib, bk, run) in enumerate(libs):
             t = sorted(times[(name, tag)])
             if not t:
                 row += "%22s" % "n/a"

@@ -70,8 +70,17 @@ __device__ __forceinline__ void vlg_epi_pace(int issued) {
 #define VLG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM>
-__global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(const GemmArgs g) {
+// PP ("ping-pong", chained BK = 32 launches only; a diagnostic option, OFF - measured 25-30 % slower than independent
+// workgroups, cause not found): a workgroup is TWO groups of four waves, each computing its own run of
+// tiles exactly as a 256-thread workgroup would (own LDS half, own virtual block id), but sharing the workgroup barrier -
+// and running half a K range apart.  The vector ALU serves the oldest wave first, so two independent workgroups on a CU do
+// not alternate: the older one streams its tiles, the younger one fills its gaps and is left alone with its own gaps
+// (epilogue store issue, auxiliary loads) exposed.  With a common barrier per K tile the older group must wait for the
+// younger every iteration, the two take the matrix pipe in turns, and one group's epilogue (cut into four slices, a
+// barrier each) always runs beside the other group's main loop.  Both groups execute the same number of barriers: the
+// second group starts with nk / 2 empty slots, the first ends with them.
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool PP = false>
+__global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(const GemmArgs g) {
     // Raised priority until the main loop starts.  It does NOT get this block's vector instructions past an older block's
     // MFMA stream (the vector ALU serves the oldest wave that has a matrix or vector instruction ready, whatever s_setprio
     // says: tools/micro/mfma_f32_valu_share.hip prio / two), but the prologue's loads and LDS writes are issued ahead of the
@@ -88,13 +97,17 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
     constexpr int NCH = BK / 8;                    // 8-deep MFMA chunks per tile
     using TA = Tile<BM, A_KC, BK>;
     using TB = Tile<BN, B_KC, BK>;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::FLOATS + TB::FLOATS)];
+    constexpr int SMEM_FLOATS = 2 * (TA::FLOATS + TB::FLOATS);
+    __shared__ __attribute__((aligned(16))) float smem_all[(PP ? 2 : 1) * SMEM_FLOATS];
+    const int grp = PP ? (int)(threadIdx.x >> 8) : 0;          // ping-pong: which of the two four-wave groups
+    float* const smem = smem_all + grp * SMEM_FLOATS;
     float* const As0 = smem;                       // As[buf] = As0 + buf * TA::FLOATS
     float* const Bs0 = smem + 2 * TA::FLOATS;      // Bs[buf] = Bs0 + buf * TB::FLOATS
 
     // XCD-aware remap: hardware deals blocks round-robin over 8 XCDs; give each XCD a
     // contiguous run of logical tiles (bijective for any grid size)
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    // (ping-pong: the second group takes the upper half of the virtual block ids, so id & 7 still says which XCD)
+    const int nwg = (PP ? 2 : 1) * (int)gridDim.x, bid = (int)blockIdx.x + grp * (int)gridDim.x;
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     // N tiles per block: the fast path of the BK = 32 kernels without bias-gradient sums (the host sets it); a compile-time 1
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
     int64_t kend = kbeg + g.kc_per_split;
     if (kend > g.Kc) kend = g.Kc;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & (GEMM_THREADS - 1), lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave - wm * WN;
 #ifdef VLG_TIMELINE
@@ -564,8 +577,13 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].y), dc, vc + j * 128, soff(2 * q + 1), 0);
                     vlg_epi_pace(2 * q + 2);
                 }
+                if constexpr (PP) __syncthreads();          // one epilogue slice per slot of the other group's main loop
             }
     };
+    if constexpr (PP) {
+        if (!fast_tile) return;                    // (never: the host launches this variant only where every block is fast)
+        if (grp == 1) for (int i = 0; i < nk / 2; ++i) __syncthreads();
+    }
     if (fast_tile) {
         // the tiles of the run: [main loop, epilogue] per tile; the next tile's bias is fetched ahead of the main loop
         for (int rt = 0; rt < run; ++rt) {
@@ -575,6 +593,9 @@ __global__ __launch_bounds__(GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kerne
             if (has_next) load_bias(n0v + BN);
             emit_fast(n0v);
             if (has_next) init_acc();
+        }
+        if constexpr (PP) {
+            if (grp == 0) for (int i = 0; i < nk / 2; ++i) __syncthreads();
         }
     } else if (full) emit(std::false_type{});
     else emit(std::true_type{});
@@ -631,7 +652,14 @@ extern "C" void vlg_debug_set_gemm_bk(int bk) { vlg_gemm_bk_forced = (bk == 16 |
 // largest divisor of the N tile count that still leaves one block per slot.  Only where EVERY block takes the fast path
 // (no edge tiles, an even number of K tiles, 32-bit spans): a block that does not computes one tile only.
 static int vlg_gemm_run_forced = -1;
-extern "C" void vlg_debug_set_gemm_run(int run) { vlg_gemm_run_forced = run; }
+static int vlg_gemm_pingpong = 0;
+// run: 0 = never chain, -1 = the library's choice, > 0 = that many; bit 16 set: chained launches as ping-pong pairs (two
+// four-wave groups per workgroup, see the kernel) instead of independent 256-thread workgroups - MEASURED 25-30 % SLOWER
+// (tools/ab/gemm_ab.py: fwd qkv 95 -> 120 us, FFN1 + GELU 139 -> 188 us), so it stays a diagnostic switch
+extern "C" void vlg_debug_set_gemm_run(int run) {
+    vlg_gemm_pingpong = (run >= 0 && (run & 0x10000)) ? 1 : 0;
+    vlg_gemm_run_forced = run < 0 ? -1 : (run & 0xffff) == 0xffff ? -1 : (run & 0xffff);
+}
 template <int BM, int BN, int BK, bool A_KC, bool B_KC>
 static int gemm_run(const GemmArgs& g, int slots) {
     if (BM != 128 || BN != 128 || g.splits != 1) return 1;
@@ -671,6 +699,14 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
     }
     const int64_t blocks = (int64_t)g.tiles_m * (g.tiles_n / g.run) * g.splits;
     if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
+    if constexpr (CAN_RUN) {
+        // chained launches: two four-wave groups per workgroup taking the matrix pipe in turns (see the kernel); the virtual
+        // block ids of a group must keep their XCD (multiple of 8 workgroups)
+        if (g.run > 1 && vlg_gemm_pingpong && (blocks % 16) == 0) {
+            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM, true>), dim3((unsigned)(blocks / 2)), dim3(2 * GEMM_THREADS), 0, s, g);
+            return vlg_last_error();
+        }
+    }
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM>), dim3((unsigned)blocks), block, 0, s, g);
     return vlg_last_error();
 }
