@@ -41,9 +41,9 @@ PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 DOMINANT = "gemm_wgrad"          # largest share of device time (profiles/r0*_kernel_stats.csv)
 GEMM_FAMILIES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_head")
 KERNEL_OF_FAMILY = {             # rocprofv3 kernel names (profiles/) for each timed family
-    "gemm_fwd": "gemm_f32_kernel<128,128,32|16,true,true,*,false>",
-    "gemm_dgrad": "gemm_f32_kernel<128,128,32|16,true,false,*,false>",
-    "gemm_wgrad": "gemm_f32_kernel<128,128,32,false,false,0,true>",
+    "gemm_fwd": "gemm_f32_kernel<128,128,32|16,true,true,*,false,false>",
+    "gemm_dgrad": "gemm_f32_kernel<128,128,32|16,true,false,*,false,false>",
+    "gemm_wgrad": "gemm_f32_kernel<128,128,32,false,false,0,true,false>",
     "gemm_head": "gemm_f32_kernel<128,32,32,..>/<32,128,32,..>",
     "embed_fwd": "embed_fwd_kernel", "embed_bwd": "embed_bwd_kernel", "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel",
     "attn_fwd": "attn16_fwd_kernel", "attn_bwd": "attn16_bwd_kernel", "loss": "layout_loss_kernel", "adam": "adam_kernel",

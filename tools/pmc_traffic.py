@@ -45,7 +45,7 @@ def main():
     import bench
     fam = {}
     for k, n, _, fb, _, wb in rows:
-        if "gemm_f32_kernel<128, 128, 32, false, false, 0, true>" in k:
+        if "gemm_f32_kernel<128, 128, 32, false, false, 0, true" in k:      # (+ the trailing ping-pong flag)
             fam["gemm_wgrad"] = fb + wb
         for key, pat in (("attn_bwd", "attn16_bwd_kernel"), ("attn_fwd", "attn16_fwd_kernel"), ("embed_fwd", "embed_fwd_kernel"),
                          ("embed_bwd", "embed_bwd_kernel"), ("loss", "layout_loss_kernel"), ("adam", "adam_kernel")):
