@@ -4,7 +4,10 @@
 Every block stamps s_memrealtime (100 MHz) at entry, main-loop start, main-loop end and exit (after its stores have
 drained) together with HW_ID / XCC_ID.  Grouped by CU this shows whether the co-resident blocks of a CU run their
 main loops and epilogues in lockstep, and how long no block of a CU has matrix work.
-    VLG_HIP_LIB=$PWD/tools/ab/libvlg_tl.so python tools/diag/gemm_timeline.py [ff1|dgelu|qkv|proj|wgrad ...]
+    cd video-layout-generation_amd/csrc && hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Xclang -target-feature -Xclang -load-store-opt \
+        -DVLG_TIMELINE -c gemm.hip -o /tmp/gemm_tl.o && hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libvlg_tl.so \
+        /tmp/gemm_tl.o $(ls *.o | grep -v '^gemm.o')
+    VLG_HIP_LIB=$PWD/tools/ab/libvlg_tl.so python tools/diag/gemm_timeline.py [ff1|dgelu|mul|dplain|qkv|proj|wgrad ...] [sweep]
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
