@@ -1,4 +1,4 @@
-// fp32 MFMA GEMMs for the dense QKV / FFN / head projections (MFMA-bound in fp32).
+// fp32 MFMA GEMMs for the dense QKV / FFN / head projections.
 //
 // One kernel template serves forward (A.W^T), data-gradient (dY.W) and weight-gradient
 // (dY^T.X, split over the token dimension) by choosing how each operand tile sits in LDS:
@@ -14,17 +14,25 @@
 // Block = 256 threads = 4 waves; 128x128 tile => each wave owns 64x64 = 2x2 MFMA tiles
 // (64 accumulator VGPRs).  Staging is global -> VGPR -> LDS, double-buffered in LDS and one tile
 // deep in registers: tile kt+1 is loaded from global one iteration ahead, written to the idle LDS
-// buffer BETWEEN the MFMAs of one chunk of tile kt (one ds_write_b128 / global_load_dwordx4 behind
-// each MFMA, pinned with sched_group_barrier), so staging never stops the matrix pipe.
-// The main loop is scheduled by hand (round 2; +5-7 % on every shape, asymptote 140 TFLOP/s = 89 %):
-//   - fragment reads are double-buffered in registers: chunk s+1's LDS reads are issued before chunk
-//     s's 16 MFMAs (hipcc alone reads two registers at a time behind an s_waitcnt every 2-4 MFMAs);
-//   - the steady-state iteration is one basic block (the last two iterations are peeled);
-//   - the iteration's one barrier sits in FRONT of the last chunk's MFMAs and the next tile's first
-//     fragments are read behind it, under those MFMAs.
+// buffer BETWEEN the MFMAs of one chunk of tile kt (one ds_write_b128 / load behind each MFMA, pinned
+// with sched_group_barrier); fragment reads are double-buffered in registers (chunk s+1's LDS reads
+// are issued before chunk s's 16 MFMAs); the iteration's one barrier sits in FRONT of the last
+// chunk's MFMAs and the next tile's first fragments are read behind it, under those MFMAs.
 // BK (contraction depth per tile) is a template parameter: 32 -> 73.7 KB LDS, 2 blocks / CU;
 // 16 -> 41 KB, 3 blocks / CU.  blockIdx is remapped so tiles sharing an A panel sit on one XCD (L2).
-// Interior blocks take an unguarded instantiation of the main loop; edge blocks clamp + select.
+//
+// THE ONE PIPE.  On gfx950 this MFMA and the vector ALU of a SIMD execute serially, oldest wave first
+// (tools/micro/mfma_f32_valu_share.hip): every vector instruction of ANY wave on the SIMD costs 8 cycles
+// of matrix time (12 for a transcendental, packed or not), memory and LDS instructions cost none, and
+// s_setprio changes nothing.  So the kernel has two paths:
+//   fast     (128x128 tiles whose block lies inside both operands; mainloop_fast / emit_fast): no vector
+//            instruction in the steady-state iteration - buffer loads with the K advance in the scalar
+//            offset, two iterations unrolled so LDS addresses are immediates, zero tiles instead of
+//            peeled tails; the bias in the accumulator start; buffer stores; GELU on packed
+//            instructions in lockstep over 8 row pairs; optionally a RUN of N tiles per block, the K loop
+//            continuing into the next tile.  151 TFLOP/s at K = 4096 (96 %), 115-143 per shape of the step.
+//   general  (edge tiles, 32-wide tiles of the head, the GELU-on-load variants; mainloop / emit): 64-bit
+//            pointers, clamps and selects - ~26 vector instructions per iteration, 141 TFLOP/s at best.
 // Algorithmic work per launch: 2*M*N*K flop; bytes 4*(M*K + N*K + M*N) (+ aux operands).
 #include "common.h"
 #include <type_traits>
