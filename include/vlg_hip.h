@@ -109,13 +109,13 @@ int vlg_layernorm_bwd_bf16(const vlg_bf16* dy, const float* x, const float* mean
                               vlg_linear_wgrad) holds PRE-activations and passes through GELU on its way to LDS - the
                               FFN hidden activation gelu(u) is then never written to HBM: the first projection stores
                               u only (plain BIAS epilogue), the second projection and its weight gradient recompute    */
-#define VLG_EPI_GELU_GRAD 1024 /* native fp32 path, with BIAS | GELU: aux_out = gelu'(pre) instead of the pre-activation itself.
+#define VLG_EPI_GELU_GRAD 1024 /* native fp32 and bf16 paths, with BIAS | GELU: aux_out = gelu'(pre) instead of the pre-activation itself.
                               The epilogue has exp(-pre^2/2) and the tail polynomial in registers anyway, and the backward
                               pass needs the pre-activation for nothing but this derivative: the data gradient of the
                               second projection then takes VLG_EPI_MUL instead of VLG_EPI_DGELU (one multiply per
                               element instead of ~20 vector instructions - which the fp32 MFMA kernels pay for in matrix
                               time, see csrc/common.h)                                                                  */
-#define VLG_EPI_MUL    2048 /* native fp32 path, vlg_linear_dgrad: C = acc * aux_in[row,col]                            */
+#define VLG_EPI_MUL    2048 /* native fp32 and bf16 paths, vlg_linear_dgrad: C = acc * aux_in[row,col]                            */
 /* bf16 ACTIVATION STORAGE (with VLG_EPI_BF16 only): the activation operands named below are vlg_bf16 arrays in
  * HBM instead of float - half the bytes of a mode that is HBM-bound.  Biases, gradient slabs, master weights and
  * the residual stream stay fp32; leading dimensions count elements.                                             */

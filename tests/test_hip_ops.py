@@ -193,10 +193,18 @@ def test_linear_gelu_grad_saved_and_mul(H, dev, M, N, K):
            H.EPI_MUL, stream())
     want = (dy.double() @ w2.double()) * uu.grad
     assert_close(du, want.float(), rtol=1e-4, atol=1e-5, what="dgrad * saved gelu'")
-    # the other modes refuse the flags instead of ignoring them
+    # the bf16 MFMA kernel takes the same flags (fp32 tensors here: operands rounded to bf16 on their way to LDS)
+    H.call("vlg_linear_fwd", ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, dsave.data_ptr(),
+           M, N, K, H.EPI_BIAS | H.EPI_GELU | H.EPI_GELU_GRAD | H.EPI_BF16, stream())
+    assert_close(c, F.gelu(pre).float(), rtol=2e-2, atol=2e-2, what="ffn gelu (grad saved, bf16 MFMA)")
+    assert_close(dsave, uu.grad.float(), rtol=2e-2, atol=2e-2, what="saved gelu' (bf16 MFMA)")
+    H.call("vlg_linear_dgrad", dyd.data_ptr(), K2, w2d.data_ptr(), N, du.data_ptr(), N, dsave.data_ptr(), M, K2, N,
+           H.EPI_MUL | H.EPI_BF16, stream())
+    assert_close(du, ((dy.double() @ w2.double()) * dsave.double().cpu()).float(), rtol=2e-2, atol=3e-2, what="dgrad * saved (bf16 MFMA)")
+    # the split-bf16 fp32 mode refuses the flags instead of ignoring them
     lib = H.load()
     assert lib.vlg_linear_fwd(ad.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), c.data_ptr(), N, 0, dsave.data_ptr(),
-                              M, N, K, H.EPI_BIAS | H.EPI_GELU | H.EPI_GELU_GRAD | H.EPI_BF16, stream()) == 1001
+                              M, N, K, H.EPI_BIAS | H.EPI_GELU | H.EPI_GELU_GRAD | H.EPI_SPLIT3, stream()) == 1001
     assert lib.vlg_linear_dgrad(dyd.data_ptr(), K2, w2d.data_ptr(), N, du.data_ptr(), N, dsave.data_ptr(), M, K2, N,
                                 H.EPI_MUL | H.EPI_SPLIT3, stream()) == 1001
     assert lib.vlg_linear_dgrad(dyd.data_ptr(), K2, w2d.data_ptr(), N, du.data_ptr(), N, 0, M, K2, N, H.EPI_MUL, stream()) == 1001

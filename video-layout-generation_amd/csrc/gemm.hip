@@ -753,8 +753,8 @@ extern "C" int vlg_linear_fwd(const void* A, int lda, const void* W, int ldw, co
     if ((epilogue & (VLG_EPI_RESID | VLG_EPI_DGELU)) && !aux_in) return VLG_ERR_SHAPE;
     if ((epilogue & VLG_EPI_GELU) && !aux_out) return VLG_ERR_SHAPE;
     if ((epilogue & VLG_EPI_MUL) != 0) return VLG_ERR_SHAPE;                                          // a dgrad epilogue
-    if ((epilogue & VLG_EPI_GELU_GRAD) && (bf16 || split3 || epilogue != (VLG_EPI_BIAS | VLG_EPI_GELU | VLG_EPI_GELU_GRAD)))
-        return VLG_ERR_SHAPE;                                                                         // native fp32 path only
+    if ((epilogue & VLG_EPI_GELU_GRAD) && (split3 || epilogue != (VLG_EPI_BIAS | VLG_EPI_GELU | VLG_EPI_GELU_GRAD)))
+        return VLG_ERR_SHAPE;                                                                         // native fp32 and bf16 paths
     const bool narrow = N <= 32;
     const bool act_gelu = (epilogue & VLG_EPI_ACT_GELU) != 0;
     epilogue &= ~VLG_EPI_ACT_GELU;
@@ -799,7 +799,7 @@ extern "C" int vlg_linear_dgrad(const void* dY, int ldy, const void* W, int ldw,
     if (io != 0 && !bf16) return VLG_ERR_SHAPE;
     if (((io & 1) && (ldy & 7)) || ((io & 2) && (ldw & 7))) return VLG_ERR_ALIGN;
     if ((epilogue == VLG_EPI_DGELU || epilogue == VLG_EPI_MUL) && !aux_in) return VLG_ERR_SHAPE;
-    if (epilogue == VLG_EPI_MUL && (bf16 || split3)) return VLG_ERR_SHAPE;                            // native fp32 path only
+    if (epilogue == VLG_EPI_MUL && split3) return VLG_ERR_SHAPE;                                      // native fp32 and bf16 paths
     if (bf16) return vlg_gemm16_dgrad(g, epilogue, io, s);
     if (split3) return vlg_gemm_split_dgrad(g, epilogue, s);
     switch (epilogue) {

@@ -157,7 +157,7 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
             for (int j = 0; j < TN; ++j) {
                 if (GUARD && col0 + j * 32 >= g.N) continue;
                 float aux[16];
-                if constexpr ((EPI & (VLG_EPI_RESID | VLG_EPI_DGELU)) != 0) {
+                if constexpr ((EPI & (VLG_EPI_RESID | VLG_EPI_DGELU | VLG_EPI_MUL)) != 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
@@ -170,9 +170,20 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
                     if (GUARD && row0 + ro >= g.M) continue;
                     const int64_t o = base + ro * g.ldc + j * 32;
                     float v = acc[i][j][r] + bv[j];
-                    if constexpr ((EPI & VLG_EPI_GELU) != 0) { st1(gAuxOut + o, v); v = gelu_f(v); }
+                    if constexpr ((EPI & VLG_EPI_GELU) != 0) {
+                        if constexpr ((EPI & VLG_EPI_GELU_GRAD) != 0) {      // aux_out = gelu'(pre) (common.h, gelu_parts): the backward
+                            float c, pd;                                     // pass then multiplies (VLG_EPI_MUL) instead of recomputing
+                            gelu_parts(v, c, pd);
+                            st1(gAuxOut + o, c + v * pd);
+                            v *= c;
+                        } else {
+                            st1(gAuxOut + o, v);
+                            v = gelu_f(v);
+                        }
+                    }
                     if constexpr ((EPI & VLG_EPI_RESID) != 0) v += aux[r];
                     if constexpr ((EPI & VLG_EPI_DGELU) != 0) v *= dgelu_f(aux[r]);
+                    if constexpr ((EPI & VLG_EPI_MUL) != 0) v *= aux[r];
                     st1(Cs + o, v);
                 }
             }
@@ -241,6 +252,11 @@ int vlg_gemm16_fwd(GemmArgs g, int epilogue, int io, hipStream_t s) {
         if (io == 7) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU, false, 7>(g, s);
         return VLG_ERR_SHAPE;
     }
+    if (epilogue == (VLG_EPI_BIAS | VLG_EPI_GELU | VLG_EPI_GELU_GRAD)) {
+        if (io == 0) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU | VLG_EPI_GELU_GRAD, false, 0>(g, s);
+        if (io == 7) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_GELU | VLG_EPI_GELU_GRAD, false, 7>(g, s);
+        return VLG_ERR_SHAPE;
+    }
     if (epilogue == (VLG_EPI_BIAS | VLG_EPI_RESID)) {
         if (io == 0) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false, 0>(g, s);
         if (io == 3) return launch16<128, 128, true, true, VLG_EPI_BIAS | VLG_EPI_RESID, false, 3>(g, s);
@@ -264,6 +280,11 @@ int vlg_gemm16_dgrad(GemmArgs g, int epilogue, int io, hipStream_t s) {
     if (epilogue == VLG_EPI_DGELU) {
         if (io == 0) return launch16<128, 128, true, false, VLG_EPI_DGELU, false, 0>(g, s);
         if (io == 6) return launch16<128, 128, true, false, VLG_EPI_DGELU, false, 6>(g, s);
+        return VLG_ERR_SHAPE;
+    }
+    if (epilogue == VLG_EPI_MUL) {
+        if (io == 0) return launch16<128, 128, true, false, VLG_EPI_MUL, false, 0>(g, s);
+        if (io == 6) return launch16<128, 128, true, false, VLG_EPI_MUL, false, 6>(g, s);
         return VLG_ERR_SHAPE;
     }
     return VLG_ERR_SHAPE;

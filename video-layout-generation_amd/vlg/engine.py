@@ -80,10 +80,10 @@ class LayoutEngine:
         # optional (native fp32 only): gelu(u) is never stored - the FFN's first projection writes the pre-activation u
         # only and the second projection / its weight gradient apply GELU while staging their operand (VLG_EPI_ACT_GELU)
         self.gelu_on_load = False      # measured slower end to end (GEMM notes): the recomputation is not hidden
-        # native fp32: the FFN's first projection stores gelu'(u) in the pre-activation buffer instead of u (VLG_EPI_GELU_GRAD;
+        # native fp32 and the bf16 modes: the FFN's first projection stores gelu'(u) in the pre-activation buffer instead of u (VLG_EPI_GELU_GRAD;
         # nothing else reads u) and the second projection's data gradient multiplies by it (VLG_EPI_MUL): ~20 vector
         # instructions per element less in a kernel that pays for each of them in matrix time (csrc/common.h)
-        self.gelu_grad_saved = precision == "fp32" and not self.gelu_on_load and os.environ.get("VLG_GELU_GRAD_SAVED", "1") != "0"
+        self.gelu_grad_saved = precision in ("fp32", "bf16", "bf16_mfma") and not self.gelu_on_load and os.environ.get("VLG_GELU_GRAD_SAVED", "1") != "0"
         self._epi_ff1 = EPI_BIAS | EPI_GELU | (hip.EPI_GELU_GRAD if self.gelu_grad_saved else 0)
         self._epi_dff2 = hip.EPI_MUL if self.gelu_grad_saved else EPI_DGELU
         self._sfx = "_bf16" if self.bf16_store else ""
