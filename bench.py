@@ -308,7 +308,9 @@ def main():
                                                   "ms_per_step": round(v["total_ms"] / 2, 3),
                                                   "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 2)}
                                               for k, v in allf.items() if k in GEMM_FAMILIES}}
-            roof_hbm = [{"kernel": KERNEL_OF_FAMILY.get(k, k), "family": k, "bound": "hbm",
+            attn = {16: "attn16", 32: "attn32"}.get(args.T, "attn")      # csrc/attention.hip: MFMA score tiles at T = 16 / 32
+            hbm_names = dict(KERNEL_OF_FAMILY, attn_fwd=attn + "_fwd_kernel", attn_bwd=attn + "_bwd_kernel")
+            roof_hbm = [{"kernel": hbm_names.get(k, k), "family": k, "bound": "hbm",
                          "achieved": round(v["bytes_per_launch"] / (v["avg_ms"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(v["bytes_per_launch"] / (v["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "algorithmic_bytes_per_launch": int(v["bytes_per_launch"]), "avg_launch_us": round(1e3 * v["avg_ms"], 2),
