@@ -47,32 +47,45 @@ struct RowIO {
     }
 };
 
+// rows a wave holds in flight per loop trip: one 1-KB row per wave leaves too few bytes in flight to cover the HBM latency
+// (8 192 resident waves x 1 KB = 8 MB against ~16 MB for 8 TB/s x 2 us), so short rows are processed LN_ROWS(E) at a time
+#define LN_ROWS(E) ((E) <= 4 ? 4 : (E) <= 8 ? 2 : 1)
+
 template <int E, bool V4, typename EY = float>
 __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     EY* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, float eps) {
-    constexpr int d = E * 64;
+    constexpr int d = E * 64, R = LN_ROWS(E);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * LN_WAVES;
     float g[E], b[E];
     RowIO<E, V4>::load(gamma, lane, g);
     RowIO<E, V4>::load(beta, lane, b);
-    for (int64_t r = wave; r < rows; r += nwaves) {
-        float v[E];
-        RowIO<E, V4>::load(x + r * d, lane, v);
-        float s = 0.f;
+    for (int64_t r0 = wave * R; r0 < rows; r0 += nwaves * R) {
+        float v[R][E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) s += v[j];
-        const float mu = wave_sum(s) * (1.0f / d);
-        float q = 0.f;
+        for (int i = 0; i < R; ++i) {                          // a short last group re-reads the last row, stores are guarded
+            const int64_t r = r0 + i < rows ? r0 + i : rows - 1;
+            RowIO<E, V4>::load(x + r * d, lane, v[i]);
+        }
 #pragma unroll
-        for (int j = 0; j < E; ++j) { const float t = v[j] - mu; q += t * t; }
-        const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / d) + eps);
+        for (int i = 0; i < R; ++i) {
+            float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < E; ++j) v[j] = (v[j] - mu) * rs * g[j] + b[j];
-        RowIO<E, V4>::store(y + r * d, lane, v);
-        if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+            for (int j = 0; j < E; ++j) s += v[i][j];
+            const float mu = wave_sum(s) * (1.0f / d);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < E; ++j) { const float t = v[i][j] - mu; q += t * t; }
+            const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / d) + eps);
+#pragma unroll
+            for (int j = 0; j < E; ++j) v[i][j] = (v[i][j] - mu) * rs * g[j] + b[j];
+            if (r0 + i < rows) {
+                RowIO<E, V4>::store(y + (r0 + i) * d, lane, v[i]);
+                if (lane == 0) { mean[r0 + i] = mu; rstd[r0 + i] = rs; }
+            }
+        }
     }
 }
 
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(
     const EY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ dres,
     float* __restrict__ dx_out, float* __restrict__ slabs, int64_t slab_stride, int64_t rows) {
-    constexpr int d = E * 64;
+    constexpr int d = E * 64, R = LN_ROWS(E);
     __shared__ float red[LN_WAVES][2 * d];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + w;
@@ -90,34 +103,43 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(
     RowIO<E, V4>::load(gamma, lane, g);
 #pragma unroll
     for (int j = 0; j < E; ++j) { dg[j] = 0.f; db[j] = 0.f; }
-    for (int64_t r = wave; r < rows; r += nwaves) {
-        float gy[E], xv[E];
-        RowIO<E, V4>::load(dy + r * d, lane, gy);
-        RowIO<E, V4>::load(x + r * d, lane, xv);
-        const float mu = mean[r], rs = rstd[r];
-        float s1 = 0.f, s2 = 0.f;
+    for (int64_t r0 = wave * R; r0 < rows; r0 += nwaves * R) {
+        float gy[R][E], xv[R][E], o[R][E], mu[R], rs[R];
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const float xh = (xv[j] - mu) * rs;
-            const float a = gy[j] * g[j];
-            dg[j] += gy[j] * xh;
-            db[j] += gy[j];
-            s1 += a;
-            s2 += a * xh;
-            xv[j] = xh;
-            gy[j] = a;
-        }
-        s1 = wave_sum(s1) * (1.0f / d);
-        s2 = wave_sum(s2) * (1.0f / d);
-        float o[E];
-        if (dres != nullptr) RowIO<E, V4>::load(dres + r * d, lane, o);
-        else {
+        for (int i = 0; i < R; ++i) {
+            const int64_t r = r0 + i < rows ? r0 + i : rows - 1;
+            RowIO<E, V4>::load(dy + r * d, lane, gy[i]);
+            RowIO<E, V4>::load(x + r * d, lane, xv[i]);
+            if (dres != nullptr) RowIO<E, V4>::load(dres + r * d, lane, o[i]);
+            else {
 #pragma unroll
-            for (int j = 0; j < E; ++j) o[j] = 0.f;
+                for (int j = 0; j < E; ++j) o[i][j] = 0.f;
+            }
+            mu[i] = mean[r];
+            rs[i] = rstd[r];
         }
 #pragma unroll
-        for (int j = 0; j < E; ++j) o[j] += rs * (gy[j] - s1 - xv[j] * s2);
-        RowIO<E, V4>::store(dx_out + r * d, lane, o);
+        for (int i = 0; i < R; ++i) {
+            const float live = r0 + i < rows ? 1.f : 0.f;      // rows past the end add nothing to dgamma / dbeta
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const float xh = (xv[i][j] - mu[i]) * rs[i];
+                const float gl = gy[i][j] * live;
+                const float a = gy[i][j] * g[j];
+                dg[j] += gl * xh;
+                db[j] += gl;
+                s1 += a;
+                s2 += a * xh;
+                xv[i][j] = xh;
+                gy[i][j] = a;
+            }
+            s1 = wave_sum(s1) * (1.0f / d);
+            s2 = wave_sum(s2) * (1.0f / d);
+#pragma unroll
+            for (int j = 0; j < E; ++j) o[i][j] += rs[i] * (gy[i][j] - s1 - xv[i][j] * s2);
+            if (r0 + i < rows) RowIO<E, V4>::store(dx_out + (r0 + i) * d, lane, o[i]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < E; ++j) {
