@@ -252,20 +252,25 @@ int vlg_rollout_input(const float* e_a, const float* seg_a, const float* img_a, 
 int vlg_conv3x3_fwd(const float* in, const float* w, const float* bias, float* out, const float* resid,
                     const float* rowmask, const float* prelu_slope, const int* rowtab, int64_t rows_out,
                     int cin_p, int cout, int cout_p, int wp_in, int act_ch, int epilogue,
-                    float* workspace /* NULL, or >= vlg_conv3x3_fwd_splits() * rows_out * cout_p floats: enables split-K */,
-                    int64_t workspace_capacity /* floats available at workspace (checked) */, void* stream);
-/* K ranges the forward uses when given a workspace (1 = no split): coarse levels of the 256-512 channel trunks */
+                    float* workspace /* NULL, or >= vlg_conv3x3_fwd_workspace() floats: enables split-K (all tiles at the coarse
+                                        levels; elsewhere the tiles beyond the last full round of 256, see csrc/conv.hip) */,
+                    int64_t workspace_capacity /* floats available at workspace (checked; too small for the tail plan = no tail
+                                                  split, too small for the coarse-level split = VLG_ERR_SHAPE) */, void* stream);
+/* K ranges the forward uses for EVERY tile when given a workspace (1 = no such split): coarse levels of the 256-512 channel trunks */
 int vlg_conv3x3_fwd_splits(int64_t rows_out, int cin_p, int cout, int cout_p);
+/* floats of workspace the forward can use for this shape (0 = none): splits * rows_out * cout_p, or the tail plan's partial tiles */
+int64_t vlg_conv3x3_fwd_workspace(int64_t rows_out, int cin_p, int cout, int cout_p);
 int vlg_conv3x3_dgrad_slabs(int64_t rows_in, int cin_p);   /* length of the slope-gradient partial vector */
 int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, const float* x_in,
                       const float* rowmask_in, const float* prelu_slope, float* da_slab,
                       const int* tap_tables, int64_t tab_stride, int64_t rows_in, int cin_p, int cout_p,
                       int wp, int act_ch, int epilogue,
-                      float* workspace /* NULL, or >= vlg_conv3x3_dgrad_splits() * rows_in * cin_p floats (split-K; used only
+                      float* workspace /* NULL, or >= vlg_conv3x3_dgrad_workspace() floats (split-K as in the forward; used only
                                           when da_slab and tap_tables are NULL, i.e. by the frozen trunks) */,
                       int64_t workspace_capacity /* floats available at workspace (checked) */,
                       int da_capacity /* floats available at da_slab, >= vlg_conv3x3_dgrad_slabs() (checked) */, void* stream);
 int vlg_conv3x3_dgrad_splits(int64_t rows_in, int cin_p, int cout_p);
+int64_t vlg_conv3x3_dgrad_workspace(int64_t rows_in, int cin_p, int cout_p);
 int vlg_conv3x3_wgrad_slabs(int64_t rows, int cin_p, int cout_p);
 int vlg_conv3x3_wgrad(const float* dout, const float* in, float* slabs, int64_t slab_stride, int64_t slab_capacity,
                       const int* rowtab, const float* prelu_slope, int64_t rows, int cin_p, int cout_p,

@@ -222,6 +222,56 @@ def test_split_k_trunk_convs(dev, b, H, W, cin, cout):
     assert rc == 1001
 
 
+@pytest.mark.parametrize("b,H,W,cin,cout,resid", [(2, 128, 128, 128, 128, False), (2, 128, 128, 64, 128, True)])
+def test_tail_split_convs(dev, b, H, W, cin, cout, resid):
+    """265 / 529 row tiles on 256 CUs: with a workspace the tiles beyond the last full round are cut along K inside the same
+    launch and summed by the finish kernel (csrc/conv.hip, conv_tail_plan) - forward with bias / residual / halo mask and
+    the ReLU' data gradient (accumulating), against the same fp64 reference as the one-block-per-tile path."""
+    from vlg import hip
+    from vlg.hip import CEPI_ACCUM, CEPI_DPRELU, CEPI_RESID
+    lib = hip.load()
+    g = torch.Generator().manual_seed(3 * cin + cout)
+    h = _Harness(dev, b, H, W, cin, cout, 1)
+    x = _away_from_kink((b, cin, H, W), g)
+    w = (torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cin * 9) ** 0.5
+    bias = (torch.rand(cout, generator=g) * 2 - 1) * 0.1
+    r = torch.randn(b, cout, H, W, generator=g)
+    rs = torch.randn(b, cout, H, W, generator=g) if resid else None
+    prior = torch.randn(b, cin, H, W, generator=g)
+    y_w, dx_w, _, _, _, _ = _reference(x, w, bias, 0.0, cin, 1, rs, r)
+    S = h.S
+    h.put(x, h.x, cin, h.gi)
+    h.put(r, h.dy, cout, h.go)
+    h.put(prior, h.dx, cin, h.gi)
+    if resid:
+        h.put(rs, h.res, cout, h.go)
+    wdev, bdev = h.pack_weight(w), bias.to(dev).contiguous()
+    zero = torch.zeros(4, device=dev)
+    need = lib.vlg_conv3x3_fwd_workspace(h.go.rows, h.cin_p, cout, h.cout_p)
+    assert lib.vlg_conv3x3_fwd_splits(h.go.rows, h.cin_p, cout, h.cout_p) == 1 and 0 < need < h.go.rows * h.cout_p, need
+    ws = torch.full((need,), float("nan"), device=dev)
+    hip.call("vlg_conv3x3_fwd", h.x.ptr, wdev.data_ptr(), bdev.data_ptr(), h.y.ptr, h.res.ptr if resid else 0, h.go.mask.data_ptr(),
+             zero.data_ptr(), 0, h.go.rows, h.cin_p, cout, h.cout_p, h.gi.wp, h.cin_p, CEPI_RESID if resid else 0,
+             ws.data_ptr(), ws.numel(), S)
+    _rel(h.get(h.y, cout, h.go), y_w, "tail-split forward")
+    assert not bool(torch.isnan(ws).all()), "the workspace was not used: the tail plan did not run"
+    yp = h.y.buf[h.go.guard * h.cout_p:(h.go.guard + h.go.rows) * h.cout_p].view(b, H + 2, W + 2, h.cout_p)
+    assert float(yp[:, -1].abs().max()) == 0 and float(yp[:, :, -1].abs().max()) == 0      # halo rows of the tail stay zero
+    # one float short: the launch falls back to one block per tile, same result
+    h.y.buf.zero_()
+    hip.call("vlg_conv3x3_fwd", h.x.ptr, wdev.data_ptr(), bdev.data_ptr(), h.y.ptr, h.res.ptr if resid else 0, h.go.mask.data_ptr(),
+             zero.data_ptr(), 0, h.go.rows, h.cin_p, cout, h.cout_p, h.gi.wp, h.cin_p, CEPI_RESID if resid else 0,
+             ws.data_ptr(), ws.numel() - 1, S)
+    _rel(h.get(h.y, cout, h.go), y_w, "forward, workspace too small for the tail plan")
+    dneed = lib.vlg_conv3x3_dgrad_workspace(h.gi.rows, h.cin_p, h.cout_p)
+    assert dneed > 0
+    ws2 = torch.full((dneed,), float("nan"), device=dev)
+    hip.call("vlg_conv3x3_dgrad", h.dy.ptr, wdev.data_ptr(), h.dx.ptr, h.x.ptr, h.gi.mask.data_ptr(), zero.data_ptr(),
+             0, 0, 0, h.gi.rows, h.cin_p, h.cout_p, h.gi.wp, h.cin_p, CEPI_DPRELU | CEPI_ACCUM, ws2.data_ptr(), ws2.numel(), 0, S)
+    _rel(h.get(h.dx, cin, h.gi), dx_w + prior.double(), "tail-split dx (accumulated)")
+    assert not bool(torch.isnan(ws2).all())
+
+
 def test_dgrad_accumulates_into_shared_input(dev):
     """A tensor consumed by two blocks (gridnet.py:51-56) collects both data gradients: VLG_CEPI_ACCUM adds."""
     from vlg import hip

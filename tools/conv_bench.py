@@ -51,16 +51,19 @@ for (hw, cin, cout) in SHAPES:
     da = torch.zeros(lib.vlg_conv3x3_dgrad_slabs(geo.rows, x.cp) + 8, device=dev)
     flop = 2.0 * b * hw * hw * cin * cout * 9
     nsp = lib.vlg_conv3x3_fwd_splits(geo.rows, x.cp, cout, y.cp)
-    ws = torch.empty(nsp * geo.rows * y.cp, device=dev) if nsp > 1 else None
+    wsn = lib.vlg_conv3x3_fwd_workspace(geo.rows, x.cp, cout, y.cp)       # all tiles split (coarse levels) or the tail plan
+    ws = torch.empty(wsn, device=dev) if wsn else None
     f = timeit(lambda: call("vlg_conv3x3_fwd", x.ptr, ptr(w), ptr(bias), y.ptr, 0, ptr(geo.mask), ptr(zero), 0, geo.rows,
                             x.cp, cout, y.cp, geo.wp, x.cp, 0, hip.ptr(ws), ws.numel() if ws is not None else 0, stream))
     dsp = lib.vlg_conv3x3_dgrad_splits(geo.rows, x.cp, y.cp)
-    dws = torch.empty(dsp * geo.rows * x.cp, device=dev) if dsp > 1 else None
-    # da = NULL when the split-K path exists (frozen trunks ask for no slope gradient), else the GridNet form
-    d = timeit(lambda: call("vlg_conv3x3_dgrad", y.ptr, ptr(w), dx.ptr, x.ptr, ptr(geo.mask), ptr(zero), 0 if dsp > 1 else ptr(da),
+    dwsn = lib.vlg_conv3x3_dgrad_workspace(geo.rows, x.cp, y.cp)
+    dws = torch.empty(dwsn, device=dev) if dwsn else None
+    # da = NULL when a split path exists (frozen trunks ask for no slope gradient), else the GridNet form
+    d = timeit(lambda: call("vlg_conv3x3_dgrad", y.ptr, ptr(w), dx.ptr, x.ptr, ptr(geo.mask), ptr(zero), 0 if dwsn else ptr(da),
                             0, 0, geo.rows, x.cp, y.cp, geo.wp, x.cp, 8, hip.ptr(dws), dws.numel() if dws is not None else 0, da.numel(), stream))
     g = timeit(lambda: call("vlg_conv3x3_wgrad", y.ptr, x.ptr, ptr(slabs), slab_stride, slabs.numel(), 0, ptr(zero), geo.rows, x.cp, y.cp,
                             geo.wp, x.cp, stream))
     print("     %4dx%-4d %3d->%-3d %7.1f us %5.1f  %7.1f us %5.1f  %7.1f us %5.1f  (%d slabs%s)" % (
         hw, hw, cin, cout, f * 1e6, flop / f / 1e12, d * 1e6, flop / d / 1e12, g * 1e6, flop / g / 1e12, n_slab,
-        (", fwd split-K %d" % nsp if nsp > 1 else "") + (", dgrad split-K %d" % dsp if dsp > 1 else "")))
+        (", fwd split-K %d" % nsp if nsp > 1 else (", fwd tail split" if wsn else "")) +
+        (", dgrad split-K %d" % dsp if dsp > 1 else (", dgrad tail split" if dwsn else ""))))

@@ -41,6 +41,12 @@ struct ConvArgs {
     int64_t kc_per_split, slab_stride, colsum_off;
     int epi;
     int act_ch;              // PReLU applies to channels < act_ch only (AddCoords channels stay linear)
+    // tail of the tile order cut along K ("data-parallel + split-K remainder"): the last tail_tiles tiles (whole row tiles)
+    // are computed by tail_splits blocks each, which store raw partial tiles to tail_ws[split][row - tail_row0][ldc];
+    // conv_finish_* sums them and applies the epilogue.  0 = every tile by one block.
+    int tail_tiles, tail_splits;
+    int64_t tail_kc, tail_row0, tail_stride;
+    float* tail_ws;
 };
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
@@ -76,17 +82,32 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * TA::FLOATS;
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int bid = blockIdx.x;
     const int ntile = g.tiles_m * g.tiles_n;
-    const int split = swz / ntile;
-    const int tile = swz - split * ntile;
+    // The K ranges of the tail tiles come FIRST in launch order (padded to a multiple of 8 blocks so that the whole tiles
+    // behind them keep block % 8 = XCD): an empty chip deals them one per CU, next to a whole tile each.  Put last, they
+    // would go two at a time to the first CUs that drain (measured: 136 short blocks cost 25 us instead of ~12).
+    const int ntail = g.tail_tiles * g.tail_splits, ntp = (ntail + 7) & ~7;
+    const int nmain = g.tail_tiles > 0 ? ntile - g.tail_tiles : (int)gridDim.x;
+    const bool part = bid < ntp;
+    if (part && bid >= ntail) return;                          // padding
+    int split, tile;
+    if (!part) {
+        const int j = bid - ntp;
+        const int q = nmain >> 3, rr = nmain & 7, xcd = j & 7;
+        const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (j >> 3);
+        split = swz / ntile;
+        tile = swz - split * ntile;
+    } else {
+        tile = nmain + bid / g.tail_splits;
+        split = bid - (tile - nmain) * g.tail_splits;
+    }
     const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
-    const int64_t kbeg = (int64_t)split * g.kc_per_split;
-    int64_t kend = kbeg + g.kc_per_split;
+    const int64_t kper = part ? g.tail_kc : g.kc_per_split;
+    const int64_t kbeg = (int64_t)split * kper;
+    int64_t kend = kbeg + kper;
     if (kend > g.Kc) kend = g.Kc;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,7 +127,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + l31;
-        bv[j] = (MODE == CONV_FWD && g.bias != nullptr) ? g.bias[col < g.N ? col : g.N - 1] : 0.f;
+        bv[j] = (MODE == CONV_FWD && g.bias != nullptr && !part) ? g.bias[col < g.N ? col : g.N - 1] : 0.f;
     }
 
     // ---- per-thread constants of the gathers.  Everything that does not change from K tile to K tile is folded
@@ -549,7 +570,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     __syncthreads();
 
     // ---- epilogue (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h)
-    float* Cs = g.C + (int64_t)split * g.slab_stride;
+    // (a K range of a tail tile stores its raw partial sums: rows are addressed as in the full tensor, so the base is moved back)
+    float* Cs = part ? g.tail_ws + (int64_t)split * g.tail_stride - g.tail_row0 * g.ldc : g.C + (int64_t)split * g.slab_stride;
+    const int epi = part ? 0 : g.epi;
+    const float* const rowmask = part ? nullptr : g.rowmask;
+    const int act_cut = part ? g.N : g.act_ch;                 // data gradient: first constant (AddCoords) channel
     const int64_t row0 = m0 + wm * TM * 32 + 4 * h;
     const int col0 = n0 + wn * TN * 32 + l31;
     float da = 0.f;
@@ -559,18 +584,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     // offset; two rows at a time on packed instructions.  The general epilogue below spends ~15 vector instructions per
     // element (64-bit offsets, bounds, flag tests): a quarter of a 32-channel tile's matrix time.
     bool fast_epi = false;
-    if constexpr (MODE != CONV_WGRAD) fast_epi = fast && (MODE != CONV_DGRAD || g.act_ch >= g.N) && g.M * (int64_t)g.ldc * 4 < (1ll << 31);
+    if constexpr (MODE != CONV_WGRAD) fast_epi = fast && (MODE != CONV_DGRAD || act_cut >= g.N) && g.M * (int64_t)g.ldc * 4 < (1ll << 31);
     if constexpr (MODE != CONV_WGRAD) {
       if (fast_epi) {
         const int m0u = __builtin_amdgcn_readfirstlane((int)m0), n0u = __builtin_amdgcn_readfirstlane(n0);
         const int cbytes = (int)(g.M * (int64_t)g.ldc * 4);
         const __amdgpu_buffer_rsrc_t dC = __builtin_amdgcn_make_buffer_rsrc(Cs, 0, cbytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t dX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux_in ? g.aux_in : g.A), 0, g.aux_in ? cbytes : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t dMk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.rowmask ? g.rowmask : g.A), 0, g.rowmask ? (int)(g.M * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t dMk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowmask ? rowmask : g.A), 0, rowmask ? (int)(g.M * 4) : 0, 0x00020000);
         const int vc = ((wm * TM * 32 + 4 * h) * g.ldc + wn * TN * 32 + l31) * 4;
         const int vm = (wm * TM * 32 + 4 * h) * 4;
-        const bool e_resid = (g.epi & VLG_CEPI_RESID) != 0, e_prelu = (g.epi & VLG_CEPI_PRELU) != 0, e_dprelu = (g.epi & VLG_CEPI_DPRELU) != 0,
-                   e_accum = (g.epi & VLG_CEPI_ACCUM) != 0, e_mask = g.rowmask != nullptr;
+        const bool e_resid = (epi & VLG_CEPI_RESID) != 0, e_prelu = (epi & VLG_CEPI_PRELU) != 0, e_dprelu = (epi & VLG_CEPI_DPRELU) != 0,
+                   e_accum = (epi & VLG_CEPI_ACCUM) != 0, e_mask = rowmask != nullptr;
         const float sel = slope <= 1.0f ? __builtin_inff() : -__builtin_inff();
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -595,7 +620,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = v2f{acc[i][j][2 * q], acc[i][j][2 * q + 1]};
                 if constexpr (MODE == CONV_FWD) {
-                    if (g.bias != nullptr) {
+                    if (g.bias != nullptr && !part) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += v2(bv[j]);
                     }
@@ -652,20 +677,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
                 const int64_t o = row * g.ldc + col;
                 float v = acc[i][j][r] + bv[j];
                 if constexpr (MODE != CONV_WGRAD) {
-                    if (g.epi & VLG_CEPI_RESID) v += g.aux_in[o];
-                    if (g.epi & VLG_CEPI_PRELU) v = prelu_f(v, slope);
-                    if (g.rowmask != nullptr) v *= g.rowmask[row];
+                    if (epi & VLG_CEPI_RESID) v += g.aux_in[o];
+                    if (epi & VLG_CEPI_PRELU) v = prelu_f(v, slope);
+                    if (rowmask != nullptr) v *= rowmask[row];
                     // data gradient: appended AddCoords channels are constants, not outputs of the producing conv -
                     // their gradient must not flow on (it would train weight rows that no forward pass uses)
-                    if (MODE == CONV_DGRAD && col >= g.act_ch) v = 0.f;
-                    if (g.epi & VLG_CEPI_DPRELU) {
+                    if (MODE == CONV_DGRAD && col >= act_cut) v = 0.f;
+                    if (epi & VLG_CEPI_DPRELU) {
                         const float x = g.aux_in[o];
-                        if (col < g.act_ch) {
+                        if (col < act_cut) {
                             da += x > 0.f ? 0.f : v * x;
                             v *= x > 0.f ? 1.0f : slope;
                         }
                     }
-                    if (g.epi & VLG_CEPI_ACCUM) v += Cs[o];
+                    if (epi & VLG_CEPI_ACCUM) v += Cs[o];
                 }
                 Cs[o] = v;
             }
@@ -698,7 +723,8 @@ template <int MODE, int BM, int BN, int BK = 32>
 static int launch_conv(ConvArgs g, hipStream_t s) {
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (g.N + BN - 1) / BN;
-    const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+    const int64_t blocks = g.tail_tiles > 0 ? (int64_t)g.tiles_m * g.tiles_n - g.tail_tiles + (((int64_t)g.tail_tiles * g.tail_splits + 7) & ~7ll)
+                                            : (int64_t)g.tiles_m * g.tiles_n * g.splits;
     if (blocks < 1 || blocks > 0x7fffffff) return VLG_ERR_SHAPE;
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, BK>), dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, s, g);
     return vlg_last_error();
@@ -730,6 +756,77 @@ static bool split_96(int64_t rows) { return (rows + 127) / 128 < 400; }
 
 static bool conv_ok(const void* p) { return p != nullptr && vlg_aligned16(p); }
 
+struct ConvTile { int bm, bn, bk; };
+
+// Tile-count quantisation.  The blocks of a CU share its matrix pipes, so a launch lasts (tiles of the busiest CU) x (time of
+// one tile): 1057 tiles on 256 CUs cost 5 tile times for 4.13 tile times of work (measured: 128 -> 128 channels at 4 x 126 x 126
+// pixels, exactly 1024 tiles, 156 us; at 4 x 128 x 128, 1057 tiles, 199 us).  Plan: the tiles beyond the last full round of 256
+// (whole row tiles) are cut along K into `splits` ranges, computed by the last blocks of the same launch into a workspace and
+// summed (+ epilogue) by the finish kernel - when the tile is long enough to pay for that second launch.
+// VLG_CONV_TAIL=0 switches it off (development).
+struct ConvTail { int tiles, splits; int64_t kc, row0, floats; };
+static bool conv_tail_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VLG_CONV_TAIL"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+static ConvTail conv_tail_plan(int64_t rows, const ConvTile t, int n_cols, int64_t kc, int ldc) {
+    ConvTail none{0, 1, 0, 0, 0};
+    if (!conv_tail_on() || (kc % t.bk) != 0) return none;
+    const int64_t tiles_m = (rows + t.bm - 1) / t.bm;
+    const int tiles_n = (n_cols + t.bn - 1) / t.bn;
+    const int64_t tiles = tiles_m * tiles_n;
+    const int64_t rem = tiles % 256;
+    if (tiles < 256 || rem == 0) return none;
+    const int64_t tail_rows_t = (rem + tiles_n - 1) / tiles_n;
+    const int64_t tail_tiles = tail_rows_t * tiles_n;
+    if (tail_tiles >= tiles) return none;
+    const int ktiles = (int)(kc / t.bk);
+    const double tile_us = 2.0 * t.bm * t.bn * (double)kc / 0.5e6;         // one tile on one CU at ~0.5 TFLOP/s (80 % of its share)
+    double best = 0.0;
+    int best_per = 0;
+    for (int sp = 2; sp <= 8; ++sp) {
+        const int per = (ktiles + sp - 1) / sp;
+        if (per * t.bk < 128) break;                                        // at least 128 of contraction per block
+        const int real = (ktiles + per - 1) / per;
+        const double rounds = (double)((tail_tiles * real + 255) / 256);
+        const double saving = tile_us * (1.0 - rounds * per / ktiles) - rounds * 3.0 - 5.0;   // 3 us per short block, 5 us finish launch
+        if (saving > best) { best = saving; best_per = per; }
+    }
+    if (best < 3.0) return none;
+    ConvTail r;
+    r.tiles = (int)tail_tiles;
+    r.splits = (ktiles + best_per - 1) / best_per;
+    r.kc = (int64_t)best_per * t.bk;
+    r.row0 = (tiles_m - tail_rows_t) * t.bm;
+    r.floats = (int64_t)r.splits * (rows - r.row0) * ldc;
+    return r;
+}
+
+// tile of a forward (n_cols = cout_p, n_valid = cout) or data-gradient (n_cols = n_valid = cin_p) launch; kc > 0 = the launch
+// may use the tail plan (a workspace was given): then 128-row tiles whenever they fill the chip once, the remainder is the plan's
+static ConvTile conv_tile(int64_t rows, int n_cols, int n_valid, int64_t kc = 0) {
+    if (n_cols == 32) return ConvTile{128, 32, conv_narrow_bk() == 16 ? 16 : 32};
+    if (n_cols == 96) return split_96(rows) ? ConvTile{128, 32, 32} : ConvTile{128, 96, 32};
+    const int bn = n_cols == 64 ? 64 : 128;
+    const int tiles_n = n_cols == 64 ? 1 : (n_valid + 127) / 128;
+    if (kc > 0) {
+        const ConvTile big{128, bn, 32};
+        const int64_t t128 = ((rows + 127) / 128) * tiles_n;
+        if (t128 >= 256 && (t128 % 256 == 0 || conv_tail_plan(rows, big, n_valid, kc, 1).tiles > 0)) return big;
+    }
+    // small grids (coarse levels, small batches) would leave CUs idle with 128-row tiles: halve the tile height
+    const bool small = few_blocks(rows, tiles_n);
+    return ConvTile{small ? 64 : 128, bn, 32};
+}
+template <int MODE>
+static int launch_conv_tile(const ConvTile t, const ConvArgs& g, hipStream_t s) {
+    if (t.bn == 32) return t.bk == 16 ? launch_conv<MODE, 128, 32, 16>(g, s) : launch_conv<MODE, 128, 32>(g, s);
+    if (t.bn == 96) return launch_conv<MODE, 128, 96>(g, s);
+    if (t.bn == 64) return t.bm == 64 ? launch_conv<MODE, 64, 64>(g, s) : launch_conv<MODE, 128, 64>(g, s);
+    return t.bm == 64 ? launch_conv<MODE, 64, 128>(g, s) : launch_conv<MODE, 128, 128>(g, s);
+}
+
 // Split-K forward for the coarse levels of the VGG / HED trunks (4 x 32 x 32 or 16 x 16 pixels, 256-512 channels): the
 // plain launch has 44-148 blocks for 256 CUs while K = 9*cin is 2304-4608, so the contraction is cut into `splits`
 // ranges, every range writes a raw partial tile to the caller's workspace and conv_finish_kernel sums them and applies
@@ -746,6 +843,12 @@ static int conv_fwd_splits(int64_t rows_out, int cin_p, int cout, int cout_p) {
 }
 extern "C" int vlg_conv3x3_fwd_splits(int64_t rows_out, int cin_p, int cout, int cout_p) {
     return conv_fwd_splits(rows_out, cin_p, cout, cout_p);
+}
+extern "C" int64_t vlg_conv3x3_fwd_workspace(int64_t rows_out, int cin_p, int cout, int cout_p) {
+    if (rows_out < 1 || cin_p < 32 || cout_p < 32) return 0;
+    const int splits = conv_fwd_splits(rows_out, cin_p, cout, cout_p);
+    if (splits > 1) return (int64_t)splits * rows_out * cout_p;
+    return conv_tail_plan(rows_out, conv_tile(rows_out, cout_p, cout, 9 * (int64_t)cin_p), cout, 9 * (int64_t)cin_p, cout_p).floats;
 }
 
 __global__ __launch_bounds__(256) void conv_finish_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride,
@@ -826,26 +929,38 @@ extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bia
                            (epilogue & VLG_CEPI_RESID) ? resid : nullptr, rowmask, out, rows_out, cout_p / 4);
         return vlg_last_error();
     }
-    if (cout_p == 32) return conv_narrow_bk() == 16 ? launch_conv<CONV_FWD, 128, 32, 16>(g, s) : launch_conv<CONV_FWD, 128, 32>(g, s);
-    if (cout_p == 96) return split_96(rows_out) ? launch_conv<CONV_FWD, 128, 32>(g, s) : launch_conv<CONV_FWD, 128, 96>(g, s);
-    // small grids (coarse levels, small batches) would leave CUs idle with 128-row tiles: halve the tile height
-    const bool small = few_blocks(rows_out, cout_p == 64 ? 1 : (cout + 127) / 128);
-    if (cout_p == 64) return small ? launch_conv<CONV_FWD, 64, 64>(g, s) : launch_conv<CONV_FWD, 128, 64>(g, s);
-    return small ? launch_conv<CONV_FWD, 64, 128>(g, s) : launch_conv<CONV_FWD, 128, 128>(g, s);
+    const bool tail_ok = workspace != nullptr && rowtab == nullptr && !(epilogue & VLG_CEPI_PRELU) && vlg_aligned16(workspace);
+    const ConvTile t = conv_tile(rows_out, cout_p, cout, tail_ok ? g.Kc : 0);
+    if (tail_ok) {
+        const ConvTail tl = conv_tail_plan(rows_out, t, cout, g.Kc, cout_p);
+        if (tl.tiles > 0 && tl.floats <= workspace_capacity) {
+            g.tail_tiles = tl.tiles; g.tail_splits = tl.splits; g.tail_kc = tl.kc; g.tail_row0 = tl.row0;
+            g.tail_stride = (rows_out - tl.row0) * (int64_t)cout_p; g.tail_ws = workspace;
+            if (int e = launch_conv_tile<CONV_FWD>(t, g, s)) return e;
+            const int64_t off = tl.row0 * (int64_t)cout_p, n4 = (rows_out - tl.row0) * (cout_p / 4);
+            hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256)), dim3(256), 0, s,
+                               workspace, tl.splits, g.tail_stride, bias, (epilogue & VLG_CEPI_RESID) ? resid + off : nullptr,
+                               rowmask ? rowmask + tl.row0 : nullptr, out + off, rows_out - tl.row0, cout_p / 4);
+            return vlg_last_error();
+        }
+    }
+    return launch_conv_tile<CONV_FWD>(t, g, s);
 }
 
 extern "C" int vlg_conv3x3_dgrad_slabs(int64_t rows_in, int cin_p) {
-    int bn = cin_p <= 128 ? cin_p : 128;                    // one column tile up to 128 channels, 128-wide tiles beyond
-    if (cin_p == 96 && split_96(rows_in)) bn = 32;
-    const int tiles_n = (cin_p + bn - 1) / bn;
-    const bool half = (cin_p == 64 || cin_p >= 128) && few_blocks(rows_in, tiles_n);
-    const int bm = half ? 64 : 128;
-    return (int)((rows_in + bm - 1) / bm) * tiles_n;
+    const ConvTile t = conv_tile(rows_in, cin_p, cin_p);       // one partial per block of the launch
+    return (int)((rows_in + t.bm - 1) / t.bm) * ((cin_p + t.bn - 1) / t.bn);
 }
 
 // K ranges of the data gradient when given a workspace: frozen trunks only (no slope gradient wanted), stride 1
 static int conv_dgrad_splits(int64_t rows_in, int cin_p, int cout_p) { return conv_fwd_splits(rows_in, cout_p, cin_p, cin_p); }
 extern "C" int vlg_conv3x3_dgrad_splits(int64_t rows_in, int cin_p, int cout_p) { return conv_dgrad_splits(rows_in, cin_p, cout_p); }
+extern "C" int64_t vlg_conv3x3_dgrad_workspace(int64_t rows_in, int cin_p, int cout_p) {
+    if (rows_in < 1 || cin_p < 32 || cout_p < 32) return 0;
+    const int splits = conv_dgrad_splits(rows_in, cin_p, cout_p);
+    if (splits > 1) return (int64_t)splits * rows_in * cin_p;
+    return conv_tail_plan(rows_in, conv_tile(rows_in, cin_p, cin_p, 9 * (int64_t)cout_p), cin_p, 9 * (int64_t)cout_p, cin_p).floats;
+}
 
 extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, const float* x_in,
                                  const float* rowmask_in, const float* prelu_slope, float* da_slab,
@@ -887,11 +1002,23 @@ extern "C" int vlg_conv3x3_dgrad(const float* dout, const float* w, float* din, 
                            epilogue & (VLG_CEPI_DPRELU | VLG_CEPI_ACCUM));
         return vlg_last_error();
     }
-    if (cin_p == 32) return conv_narrow_bk() == 16 ? launch_conv<CONV_DGRAD, 128, 32, 16>(g, s) : launch_conv<CONV_DGRAD, 128, 32>(g, s);
-    if (cin_p == 96) return split_96(rows_in) ? launch_conv<CONV_DGRAD, 128, 32>(g, s) : launch_conv<CONV_DGRAD, 128, 96>(g, s);
-    const bool small = few_blocks(rows_in, cin_p == 64 ? 1 : (cin_p + 127) / 128);
-    if (cin_p == 64) return small ? launch_conv<CONV_DGRAD, 64, 64>(g, s) : launch_conv<CONV_DGRAD, 128, 64>(g, s);
-    return small ? launch_conv<CONV_DGRAD, 64, 128>(g, s) : launch_conv<CONV_DGRAD, 128, 128>(g, s);
+    const bool tail_ok = workspace != nullptr && da_slab == nullptr && tap_tables == nullptr && vlg_aligned16(workspace);
+    const ConvTile t = conv_tile(rows_in, cin_p, cin_p, tail_ok ? g.Kc : 0);
+    if (tail_ok) {
+        const ConvTail tl = conv_tail_plan(rows_in, t, cin_p, g.Kc, cin_p);
+        if (tl.tiles > 0 && tl.floats <= workspace_capacity) {
+            g.tail_tiles = tl.tiles; g.tail_splits = tl.splits; g.tail_kc = tl.kc; g.tail_row0 = tl.row0;
+            g.tail_stride = (rows_in - tl.row0) * (int64_t)cin_p; g.tail_ws = workspace;
+            if (int e = launch_conv_tile<CONV_DGRAD>(t, g, s)) return e;
+            const int64_t off = tl.row0 * (int64_t)cin_p, n4 = (rows_in - tl.row0) * (cin_p / 4);
+            hipLaunchKernelGGL(conv_finish_dgrad_kernel, dim3((unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256)), dim3(256), 0, s,
+                               workspace, tl.splits, g.tail_stride, x_in ? x_in + off : nullptr, rowmask_in ? rowmask_in + tl.row0 : nullptr,
+                               prelu_slope ? 1.0f : 0.0f, prelu_slope, din + off, rows_in - tl.row0, cin_p / 4, act_ch,
+                               epilogue & (VLG_CEPI_DPRELU | VLG_CEPI_ACCUM));
+            return vlg_last_error();
+        }
+    }
+    return launch_conv_tile<CONV_DGRAD>(t, g, s);
 }
 
 // row-tile height of the weight gradient: all of Cout for the GridNet widths (one pass over the gathered activation

@@ -168,10 +168,14 @@ class GridNetHIP:
         self.seg = self._block("lateral_out_seg", "lateral", x0, seg_out)
         self.img = self._block("lateral_out_img", "lateral", x0, img_out)
         self._alloc_params(params_from)
+        lib = hip.load()
+        # workspace of the stride-1 convolutions' tail split (tiles beyond the last full round of 256 CUs, csrc/conv.hip)
+        self.ws_n = max([lib.vlg_conv3x3_fwd_workspace(c.out.geo.rows, c.x.cp, c.cout, c.out.cp)
+                         for c in self.tape if isinstance(c, _Conv) and c.stride == 1] + [0])
+        self.ws = torch.empty(self.ws_n, dtype=torch.float32, device=device) if self.ws_n else None
         self.forward_only = params_from is not None
         if self.forward_only:
             return
-        lib = hip.load()
         # Backward scratch: every convolution owns a region of the slab arena (weight-gradient partials) and, if a PReLU
         # precedes it, of the slope-gradient arena; two table-driven launches at the end of backward() reduce them all
         # (vlg_reduce_slabs_table / vlg_sum_partials_table) instead of two tiny launches per convolution.
@@ -358,7 +362,7 @@ class GridNetHIP:
                 call("vlg_conv3x3_fwd", op.x.ptr, self._pp(op.w_off), self._pp(op.b_off), op.out.ptr,
                      op.resid.ptr if op.resid is not None else 0, ptr(go.mask),
                      self._pp(self.p_off[op.prelu]) if op.prelu else 0, rowtab, go.rows, op.x.cp, op.cout, op.out.cp,
-                     gx.wp, op.act_ch, CEPI_RESID if op.resid is not None else 0, 0, 0, s)
+                     gx.wp, op.act_ch, CEPI_RESID if op.resid is not None else 0, ptr(self.ws), self.ws_n, s)
             else:
                 _, src, dst = op
                 call("vlg_upsample2x_fwd", src.ptr, dst.ptr, src.geo.b, src.geo.H, src.geo.W, src.cp, s)

@@ -64,9 +64,11 @@ SIGNATURES = {
     "vlg_rollout_input": (I, [P, P, P, P, P, P, P, I, L, P]),
     "vlg_conv3x3_fwd": (I, [P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, P, L, P]),
     "vlg_conv3x3_fwd_splits": (I, [L, I, I, I]),
+    "vlg_conv3x3_fwd_workspace": (L, [L, I, I, I]),
     "vlg_conv3x3_dgrad_slabs": (I, [L, I]),
     "vlg_conv3x3_dgrad": (I, [P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, P, L, I, P]),
     "vlg_conv3x3_dgrad_splits": (I, [L, I, I]),
+    "vlg_conv3x3_dgrad_workspace": (L, [L, I, I]),
     "vlg_conv3x3_wgrad_slabs": (I, [L, I, I]),
     "vlg_conv3x3_wgrad": (I, [P, P, P, L, L, P, P, L, I, I, I, I, P]),
     "vlg_nchw_to_padded": (I, [P, P, I, I, I, I, I, I, P]),

@@ -75,11 +75,9 @@ class HNEDHIP:
         off += 4
         self.params = torch.zeros(off, dtype=torch.float32, device=device) if params_from is None else params_from.params
         self.score = [torch.empty(batch, H >> k, W >> k, dtype=torch.float32, device=device) for k in range(5)]
-        # split-K workspace of the coarse levels (vlg_conv3x3_fwd_splits partial tiles; None when no conv splits)
+        # split-K workspace (coarse levels: every tile; elsewhere the tiles beyond the last full round of 256 - csrc/conv.hip)
         lib = hip.load()
-        need = max([lib.vlg_conv3x3_fwd_splits(tout.geo.rows, tin.cp, cout, tout.cp) * tout.geo.rows * tout.cp
-                    for _, tin, tout, _, cout, _, _ in self.convs
-                    if lib.vlg_conv3x3_fwd_splits(tout.geo.rows, tin.cp, cout, tout.cp) > 1] + [0])
+        need = max([lib.vlg_conv3x3_fwd_workspace(tout.geo.rows, tin.cp, cout, tout.cp) for _, tin, tout, _, cout, _, _ in self.convs] + [0])
         self.ws = torch.empty(need, dtype=torch.float32, device=device) if need else None
         self.ws_n = need
         arr = ctypes.c_float * 3

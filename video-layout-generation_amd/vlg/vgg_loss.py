@@ -84,12 +84,10 @@ class VggLossHIP:
         self.params = torch.zeros(off, dtype=torch.float32, device=device)
         self.scratch = torch.zeros(4096, dtype=torch.float32, device=device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=device)
-        # split-K workspace of the coarse levels (vlg_conv3x3_fwd_splits partial tiles; None when no conv splits)
+        # split-K workspace (coarse levels: every tile; elsewhere the tiles beyond the last full round of 256 - csrc/conv.hip)
         lib = hip.load()
-        need = max([lib.vlg_conv3x3_fwd_splits(op[3].geo.rows, op[2].cp, op[5], op[3].cp) * op[3].geo.rows * op[3].cp
-                    for op in self.ops if op[0] == "conv" and lib.vlg_conv3x3_fwd_splits(op[3].geo.rows, op[2].cp, op[5], op[3].cp) > 1] +
-                   [lib.vlg_conv3x3_dgrad_splits(op[2].geo.rows, op[2].cp, op[3].cp) * op[2].geo.rows * op[2].cp
-                    for op in self.ops if op[0] == "conv" and lib.vlg_conv3x3_dgrad_splits(op[2].geo.rows, op[2].cp, op[3].cp) > 1] + [0])
+        need = max([lib.vlg_conv3x3_fwd_workspace(op[3].geo.rows, op[2].cp, op[5], op[3].cp) for op in self.ops if op[0] == "conv"] +
+                   [lib.vlg_conv3x3_dgrad_workspace(op[2].geo.rows, op[2].cp, op[3].cp) for op in self.ops if op[0] == "conv"] + [0])
         self.ws = torch.empty(need, dtype=torch.float32, device=device) if need else None
         self.ws_n = need
 
