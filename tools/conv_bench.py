@@ -13,6 +13,8 @@ from vlg.gridnet import _Geo, _PT
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+ONLY = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None      # indices into SHAPES
+NOACT = os.environ.get("CONV_BENCH_NOACT") == "1"                                   # no activation on load (slope pointer NULL)
 dev = torch.device("cuda:0")
 lib = hip.load()
 ptr = lambda t: t.data_ptr()
@@ -37,7 +39,9 @@ def timeit(fn, n=10):
 
 
 print("b=%d  %-18s %10s %10s %10s   (TFLOP/s algorithmic; fp32 MFMA peak 157.3)" % (b, "HxW cin->cout", "fwd", "dgrad", "wgrad"))
-for (hw, cin, cout) in SHAPES:
+for si, (hw, cin, cout) in enumerate(SHAPES):
+    if ONLY is not None and si not in ONLY:
+        continue
     geo = _Geo(b, hw, hw, dev)
     x, y = _PT(geo, cin, dev, False), _PT(geo, cout, dev, False)
     x.buf.normal_(); y.buf.normal_()
@@ -53,7 +57,7 @@ for (hw, cin, cout) in SHAPES:
     nsp = lib.vlg_conv3x3_fwd_splits(geo.rows, x.cp, cout, y.cp)
     wsn = lib.vlg_conv3x3_fwd_workspace(geo.rows, x.cp, cout, y.cp)       # all tiles split (coarse levels) or the tail plan
     ws = torch.empty(wsn, device=dev) if wsn else None
-    f = timeit(lambda: call("vlg_conv3x3_fwd", x.ptr, ptr(w), ptr(bias), y.ptr, 0, ptr(geo.mask), ptr(zero), 0, geo.rows,
+    f = timeit(lambda: call("vlg_conv3x3_fwd", x.ptr, ptr(w), ptr(bias), y.ptr, 0, ptr(geo.mask), 0 if NOACT else ptr(zero), 0, geo.rows,
                             x.cp, cout, y.cp, geo.wp, x.cp, 0, hip.ptr(ws), ws.numel() if ws is not None else 0, stream))
     dsp = lib.vlg_conv3x3_dgrad_splits(geo.rows, x.cp, y.cp)
     dwsn = lib.vlg_conv3x3_dgrad_workspace(geo.rows, x.cp, y.cp)
@@ -61,7 +65,7 @@ for (hw, cin, cout) in SHAPES:
     # da = NULL when a split path exists (frozen trunks ask for no slope gradient), else the GridNet form
     d = timeit(lambda: call("vlg_conv3x3_dgrad", y.ptr, ptr(w), dx.ptr, x.ptr, ptr(geo.mask), ptr(zero), 0 if dwsn else ptr(da),
                             0, 0, geo.rows, x.cp, y.cp, geo.wp, x.cp, 8, hip.ptr(dws), dws.numel() if dws is not None else 0, da.numel(), stream))
-    g = timeit(lambda: call("vlg_conv3x3_wgrad", y.ptr, x.ptr, ptr(slabs), slab_stride, slabs.numel(), 0, ptr(zero), geo.rows, x.cp, y.cp,
+    g = timeit(lambda: call("vlg_conv3x3_wgrad", y.ptr, x.ptr, ptr(slabs), slab_stride, slabs.numel(), 0, 0 if NOACT else ptr(zero), geo.rows, x.cp, y.cp,
                             geo.wp, x.cp, stream))
     print("     %4dx%-4d %3d->%-3d %7.1f us %5.1f  %7.1f us %5.1f  %7.1f us %5.1f  (%d slabs%s)" % (
         hw, hw, cin, cout, f * 1e6, flop / f / 1e12, d * 1e6, flop / d / 1e12, g * 1e6, flop / g / 1e12, n_slab,

@@ -130,13 +130,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
         bv[j] = (MODE == CONV_FWD && g.bias != nullptr && !part) ? g.bias[col < g.N ? col : g.N - 1] : 0.f;
     }
 
+    // which main loop this launch takes (block-uniform; decided first so that the general loop's per-thread gather
+    // constants - 64-bit pointer arithmetic, ~150 vector instructions - are not computed by blocks that never use them:
+    // a 128 x 32 tile with K = 288 has only 144 MFMAs per wave to hide them behind)
+    bool fast = false;
+    if constexpr (MODE != CONV_WGRAD && BM >= 64) {
+        const int pad = g.wp + 1;
+        const int64_t a_bytes = (g.M + 2 * (int64_t)pad) * g.lda * 4;
+        const int64_t b_bytes = (MODE == CONV_FWD ? (int64_t)g.N : (int64_t)g.cin) * g.ldb * 4;
+        fast = g.rowtab == nullptr && g.wp > 0 && (g.N % BN) == 0 && a_bytes + (int64_t)BM * g.lda * 4 < (1ll << 31) && b_bytes < (1ll << 31) &&
+               (MODE != CONV_FWD || g.act_ch >= g.cin) && ((kend - kbeg) % BK) == 0;
+    }
+    if constexpr (MODE == CONV_WGRAD) {
+        const int pad = g.wp + 1;
+        const int64_t a_bytes = g.Kc * (int64_t)g.lda * 4, b_bytes = (g.Kc + 2 * (int64_t)pad) * g.ldb * 4;
+        fast = g.rowtab == nullptr && g.wp > 0 && g.act_ch >= g.cin && a_bytes < (1ll << 31) && b_bytes < (1ll << 31) &&
+               (int64_t)g.M * g.ldc * 4 < (1ll << 31) && (kbeg % BK) == 0;
+    }
+
     // ---- per-thread constants of the gathers.  Everything that does not change from K tile to K tile is folded
     // into per-thread base pointers here; a K tile then adds ONE wave-uniform offset (tap shift and channel block),
     // which the scalar unit tracks with two running counters instead of a division per tile.
     const float* pa[TA::NV];                                   // forward / data gradient: rows of A (fixed across K tiles)
     const float* pb[TB::NV];
     int arow[TA::NV];                                          // data gradient of a stride-2 conv: row -> per-tap table index
-    if constexpr (MODE != CONV_WGRAD) {
+    if (MODE != CONV_WGRAD && !fast) {
 #pragma unroll
         for (int i = 0; i < TA::NV; ++i) {
             int64_t r = m0 + ((tid + GEMM_THREADS * i) / KPR);
@@ -161,7 +179,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     int64_t bcoloff[TB::NV];
     int bch[TB::NV];
     float4 bslope[TB::NV];                                     // slopes of this thread's four channels (fixed across K tiles)
-    if constexpr (MODE == CONV_WGRAD) {
+    if (MODE == CONV_WGRAD && !fast) {
 #pragma unroll
         for (int i = 0; i < TA::NV; ++i) {
             const int idx = tid + GEMM_THREADS * i;
@@ -311,13 +329,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     // the channel block and the float4 number in the scalar offset; the descriptor ends at the last row any tap of a valid
     // output row can reach, so the rows a partial row tile reads beyond it come back as zeros), two iterations unrolled (LDS
     // addresses are immediates), the tap / channel counters on the scalar unit, PReLU as a packed multiply + one med3.
-    bool fast = false;
     if constexpr (MODE != CONV_WGRAD && BM >= 64) {
         const int pad = g.wp + 1;
         const int64_t a_bytes = (g.M + 2 * (int64_t)pad) * g.lda * 4;
         const int64_t b_bytes = (MODE == CONV_FWD ? (int64_t)g.N : (int64_t)g.cin) * g.ldb * 4;
-        fast = g.rowtab == nullptr && g.wp > 0 && (g.N % BN) == 0 && a_bytes + (int64_t)BM * g.lda * 4 < (1ll << 31) && b_bytes < (1ll << 31) &&
-               (MODE != CONV_FWD || g.act_ch >= g.cin) && ((kend - kbeg) % BK) == 0;
         if (fast) {
             const int lda = g.lda, ldb = g.ldb;
             const __amdgpu_buffer_rsrc_t da = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A - (int64_t)pad * lda), 0, (int)a_bytes, 0x00020000);
@@ -443,8 +458,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     if constexpr (MODE == CONV_WGRAD) {
         const int pad = g.wp + 1;
         const int64_t a_bytes = g.Kc * (int64_t)g.lda * 4, b_bytes = (g.Kc + 2 * (int64_t)pad) * g.ldb * 4;
-        fast = g.rowtab == nullptr && g.wp > 0 && g.act_ch >= g.cin && a_bytes < (1ll << 31) && b_bytes < (1ll << 31) &&
-               (int64_t)g.M * g.ldc * 4 < (1ll << 31) && (kbeg % BK) == 0;
         if (fast) {
             const int lda = g.lda, ldb = g.ldb;
             const __amdgpu_buffer_rsrc_t da = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)a_bytes, 0x00020000);
