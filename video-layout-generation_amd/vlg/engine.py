@@ -224,15 +224,35 @@ class LayoutEngine:
         # second option: the bandwidth-bound kernels of backward (layer-norm backward, attention backward) run on the side
         # stream BESIDE the weight-gradient GEMM that does not depend on them (see backward)
         self.overlap_small = os.environ.get("VLG_OVERLAP_SMALL", "0") == "1"
+        # Default (VLG_GROUP_REDUCE=1, single-stream backward): the partial-sum producers of one bucket (a layer: four weight
+        # gradients + two layer-norms) write side by side into ONE arena and ONE table-driven launch (vlg_reduce_slabs_table,
+        # the form the GridNet path uses) reduces them all when the bucket is complete: 27 launches of ~5.5 us -> 6 per step.
+        self.group_reduce = (os.environ.get("VLG_GROUP_REDUCE", "1") == "1" and not self.async_reduce and
+                             not self.overlap_wgrad and not self.overlap_small)
+        if self.group_reduce:
+            pad = lambda v: (v + 3) // 4 * 4
+            layer = sum(pad(v) for v in need[2:6]) + 2 * pad(need[1])
+            head = pad(need[6]) + pad(need[1])
+            self.garena = torch.empty(max(layer, head, pad(need[0])), **f32)
+            self._goff = 0
+            self._grows: list = []
+            self._gtables: Dict[tuple, torch.Tensor] = {}
 
     # --------------------------------------------------------------------- helpers
     @staticmethod
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
-    def _arena(self, kind: str) -> torch.Tensor:
-        """the slab arena the next producer of this family writes: the current stream first waits for the reduction that
-        last read it"""
+    def _arena(self, kind: str, need: int = 0) -> torch.Tensor:
+        """the slab arena the next producer of this family writes (`need` floats): the current stream first waits for the
+        reduction that last read it; with grouped reductions, the next free range of the bucket's arena"""
+        if self.group_reduce:
+            off = self._goff
+            if off + need > self.garena.numel():
+                raise RuntimeError("partial-sum arena of %d floats is too small for %d more" % (self.garena.numel(), need))
+            self._goff = off + (need + 3) // 4 * 4
+            self._gcur = self.garena.data_ptr() + 4 * off
+            return self.garena[off:off + need]
         i = self._arena_turn[kind]
         e = self._arena_busy[kind][i]
         if e is not None:
@@ -243,9 +263,12 @@ class LayoutEngine:
     def _reduce(self, kind: str, stride: int, n_slabs: int, dst_off: int, dst_len: int) -> None:
         """sum the slabs the producer just launched on the current stream wrote into its arena -> grads[dst_off : +dst_len];
         on the reduction stream (ordered behind the producer by an event) unless VLG_ASYNC_REDUCE=0"""
+        dst = self.grads.data_ptr() + 4 * dst_off
+        if self.group_reduce:
+            self._grows.append((self._gcur, stride, n_slabs, dst, dst_len))
+            return
         i = self._arena_turn[kind]
         arena = self._arenas[kind][i]
-        dst = self.grads.data_ptr() + 4 * dst_off
         if not self.async_reduce:
             call("vlg_reduce_slabs", ptr(arena), stride, n_slabs, dst, dst_len, self._stream())
             return
@@ -266,7 +289,19 @@ class LayoutEngine:
         self._reduce_pending = None
 
     def _join_reduces(self) -> None:
-        """the current stream waits for every slab reduction issued so far (they run in order on one stream)"""
+        """the current stream waits for every slab reduction issued so far (they run in order on one stream); grouped
+        reductions: the bucket's one launch is issued here, on the current stream"""
+        if self.group_reduce:
+            if self._grows:
+                key = tuple(self._grows)
+                table = self._gtables.get(key)
+                if table is None:                                   # shapes are static per batch geometry: built once
+                    table = torch.tensor([v for row in key for v in row], dtype=torch.int64, device=self.device)
+                    self._gtables[key] = table
+                call("vlg_reduce_slabs_table", ptr(table), len(key), 128, self._stream())
+                self._grows = []
+            self._goff = 0
+            return
         if self._reduce_pending is not None:
             torch.cuda.current_stream(self.device).wait_event(self._reduce_pending)
             self._reduce_pending = None
@@ -307,7 +342,7 @@ class LayoutEngine:
         lib = hip.load()
         stride = N * K + N
         n_slabs = lib.vlg_linear_wgrad_slabs_for(M, N, K, self.gemm_flags)
-        arena = self._arena("w")
+        arena = self._arena("w", n_slabs * stride)
         s = self._stream()
         self._timed("gemm_wgrad" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_wgrad", ptr(dy), N, ptr(x),
                     K, ptr(arena), stride, arena.numel(), M, N, K, self.gemm_flags | self._storage_bits(dy, x) | extra, s,
@@ -324,7 +359,7 @@ class LayoutEngine:
         d = self.cfg.d
         lib = hip.load()
         n_slabs = lib.vlg_layernorm_bwd_slabs(M)
-        arena = self._arena("s")
+        arena = self._arena("s", n_slabs * 2 * d)
         s = self._stream()
         self._timed("ln_bwd", 0.0, "vlg_layernorm_bwd_bf16" if dy.dtype == torch.bfloat16 else "vlg_layernorm_bwd", ptr(dy), ptr(x), ptr(stat[0]),
                     ptr(stat[1]), ptr(self.p(gname)), ptr(dres), ptr(dx_out), ptr(arena), 2 * d, arena.numel(), M, d, s,
@@ -438,9 +473,10 @@ class LayoutEngine:
         on_side(("dout",), lambda: self._wgrad(self.dout, self.xf, "head_w", M, cfg.n_out, d))
         self._dgrad(self.dout, self.pw("head_w"), self.dh, M, cfg.n_out, d)
         self._ln_bwd(self.dh, self.x[L], self.stats[2 * L], "lnf_g", None, self.dx, M)
-        if reducer is not None:
+        if reducer is not None or self.group_reduce:
             join()
             self._join_reduces()
+        if reducer is not None:
             reducer.ready("head")
         if self.overlap_small and not self.overlap_wgrad:
             self._backward_layers_paired(B, T, N, M, reducer)
@@ -469,9 +505,10 @@ class LayoutEngine:
             self._dgrad(self.dqkv, self.pw(pre + "qkv_w"), self.dh, M, 3 * d, d)
             before_write("dx")
             self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)
-            if reducer is not None:
+            if reducer is not None or self.group_reduce:
                 join()
                 self._join_reduces()
+            if reducer is not None:
                 reducer.ready("l%d" % l)
         join()
         self._backward_tail(batch, B, T, N, M, reducer)
@@ -481,7 +518,7 @@ class LayoutEngine:
         lib = hip.load()
         s = self._stream()
         emb_len = self.layout["l0.ln1_g"][0]
-        arena = self._arena("s")
+        arena = self._arena("s", lib.vlg_embed_bwd_slabs() * emb_len)
         self._timed("embed_bwd", 0.0, "vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(arena),
                     emb_len, arena.numel(), B, T, N, d, cfg.vocab, s, nbytes=4.0 * M * d + 24.0 * M)
         self._reduce("s", emb_len, lib.vlg_embed_bwd_slabs(), 0, emb_len)
