@@ -268,20 +268,23 @@ def test_captured_step_replays_bitwise(dev, precision):
         assert torch.equal(graphed.params_bf16, graphed.params.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("option", ["VLG_OVERLAP_WGRAD", "VLG_ASYNC_REDUCE", "VLG_OVERLAP_SMALL"])
-def test_stream_options_do_not_change_results(dev, option, monkeypatch):
-    """The engine's multi-stream options (weight gradients on a second stream, slab reductions on a stream of their own,
-    bandwidth-bound kernels beside the weight gradients) only reorder launches across streams: parameters and losses after
-    three steps must be bit for bit those of the single-stream step."""
+@pytest.mark.parametrize("option,value", [("VLG_OVERLAP_WGRAD", "1"), ("VLG_GROUP_REDUCE", "0"), ("VLG_OVERLAP_SMALL", "1")])
+def test_stream_options_do_not_change_results(dev, option, value, monkeypatch):
+    """The engine's launch-order options (weight gradients on a second stream, every partial-sum reduction as a launch of
+    its own behind its producer instead of one table-driven launch per bucket, bandwidth-bound kernels beside the weight
+    gradients) only reorder or regroup launches: parameters and losses after three steps must be bit for bit those of
+    the default step."""
     from vlg.engine import LayoutEngine
     from vlg.spec import LayoutConfig
     cfg = LayoutConfig(B=4, T=16, N=24, d=256, n_layers=2)
     batches = [to_dev(O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=70 + i), dev) for i in range(3)]
     plain = LayoutEngine(cfg, dev)
-    monkeypatch.setenv(option, "1")
+    assert plain.group_reduce
+    monkeypatch.setenv(option, value)
     opt = LayoutEngine(cfg, dev)
     monkeypatch.delenv(option)
-    assert {"VLG_OVERLAP_WGRAD": opt.overlap_wgrad, "VLG_ASYNC_REDUCE": opt.async_reduce, "VLG_OVERLAP_SMALL": opt.overlap_small}[option]
+    assert {"VLG_OVERLAP_WGRAD": opt.overlap_wgrad, "VLG_GROUP_REDUCE": not opt.group_reduce, "VLG_OVERLAP_SMALL": opt.overlap_small}[option]
+    assert not opt.group_reduce
     for b in batches:
         lp = plain.train_step(b).clone()
         lo = opt.train_step(b).clone()

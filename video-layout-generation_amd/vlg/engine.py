@@ -197,24 +197,11 @@ class LayoutEngine:
         self.du = torch.empty(M, ff, **act)
         self.dqkv = torch.empty(M, 3 * d, **act)
         self.loss_scratch = torch.zeros(lib.vlg_layout_loss_scratch(), **f32)
-        # one slab arena shared by every partial-sum producer (each is reduced before the next writes)
+        # partial-sum ("slab") arenas: floats needed by the embedding, a layer-norm, and each weight-gradient shape
         emb_len = self.layout["l0.ln1_g"][0]
         need = [lib.vlg_embed_bwd_slabs() * emb_len, lib.vlg_layernorm_bwd_slabs(M) * 2 * d]
         for (n, k) in ((3 * d, d), (d, d), (ff, d), (d, ff), (cfg.n_out, d)):
             need.append(lib.vlg_linear_wgrad_slabs_for(M, n, k, self.gemm_flags) * (n * k + n))
-        self.slabs = torch.empty(max(need[:2]), **f32)          # partial sums written on the main stream (layer-norm, embedding)
-        self.slabs_w = torch.empty(max(need[2:]), **f32)        # weight-gradient partials (written on the side stream in backward)
-        # Option (VLG_ASYNC_REDUCE=1): the slab reductions (27 launches of ~5 us per step) on a stream of their own, beside the
-        # next kernels of backward - nothing but the optimizer (and the gradient all-reduce) reads their results; each
-        # producer family then alternates between two arenas.  MEASURED SLOWER (5.65 -> 5.80 ms per step, one box): the
-        # event hand-offs between the two queues cost more than the 5 us links they take out of the chain.  OFF.
-        self.async_reduce = os.environ.get("VLG_ASYNC_REDUCE", "0") == "1"
-        self.reduce_stream = torch.cuda.Stream(device=self.device)
-        self._arenas = {"w": [self.slabs_w, torch.empty_like(self.slabs_w) if self.async_reduce else self.slabs_w],
-                        "s": [self.slabs, torch.empty_like(self.slabs) if self.async_reduce else self.slabs]}
-        self._arena_turn = {"w": 0, "s": 0}
-        self._arena_busy = {"w": [None, None], "s": [None, None]}
-        self._reduce_pending = None
         # option: backward can run the weight gradients on a second HIP stream, concurrently with the data-gradient chain
         # (see backward).  Measured -1.7 % step time at the metric shape (6.12 -> 6.02 ms): a 512-block launch takes every
         # CU slot, so the other stream's kernel only overlaps its tail.  OFF by default: with two kernels sharing the chip
@@ -227,8 +214,7 @@ class LayoutEngine:
         # Default (VLG_GROUP_REDUCE=1, single-stream backward): the partial-sum producers of one bucket (a layer: four weight
         # gradients + two layer-norms) write side by side into ONE arena and ONE table-driven launch (vlg_reduce_slabs_table,
         # the form the GridNet path uses) reduces them all when the bucket is complete: 27 launches of ~5.5 us -> 6 per step.
-        self.group_reduce = (os.environ.get("VLG_GROUP_REDUCE", "1") == "1" and not self.async_reduce and
-                             not self.overlap_wgrad and not self.overlap_small)
+        self.group_reduce = os.environ.get("VLG_GROUP_REDUCE", "1") == "1" and not self.overlap_wgrad and not self.overlap_small
         if self.group_reduce:
             pad = lambda v: (v + 3) // 4 * 4
             layer = sum(pad(v) for v in need[2:6]) + 2 * pad(need[1])
@@ -237,6 +223,9 @@ class LayoutEngine:
             self._goff = 0
             self._grows: list = []
             self._gtables: Dict[tuple, torch.Tensor] = {}
+        else:   # one arena per producer family, each reduced right behind its producer (before the next one writes)
+            self.slabs = torch.empty(max(need[:2]), **f32)          # layer-norm, embedding (main stream)
+            self.slabs_w = torch.empty(max(need[2:]), **f32)        # weight gradients (the side stream in a two-stream backward)
 
     # --------------------------------------------------------------------- helpers
     @staticmethod
@@ -244,8 +233,9 @@ class LayoutEngine:
         return torch.cuda.current_stream().cuda_stream
 
     def _arena(self, kind: str, need: int = 0) -> torch.Tensor:
-        """the slab arena the next producer of this family writes (`need` floats): the current stream first waits for the
-        reduction that last read it; with grouped reductions, the next free range of the bucket's arena"""
+        """the slab arena the next partial-sum producer writes (`need` floats).  Grouped reductions: the next free range of the
+        bucket's arena.  Otherwise one arena per producer family ("w": weight gradients, "s": layer-norm / embedding), whose
+        previous contents were reduced on the same stream right behind their producer."""
         if self.group_reduce:
             off = self._goff
             if off + need > self.garena.numel():
@@ -253,58 +243,31 @@ class LayoutEngine:
             self._goff = off + (need + 3) // 4 * 4
             self._gcur = self.garena.data_ptr() + 4 * off
             return self.garena[off:off + need]
-        i = self._arena_turn[kind]
-        e = self._arena_busy[kind][i]
-        if e is not None:
-            torch.cuda.current_stream(self.device).wait_event(e)
-            self._arena_busy[kind][i] = None
-        return self._arenas[kind][i]
+        return self.slabs_w if kind == "w" else self.slabs
 
     def _reduce(self, kind: str, stride: int, n_slabs: int, dst_off: int, dst_len: int) -> None:
-        """sum the slabs the producer just launched on the current stream wrote into its arena -> grads[dst_off : +dst_len];
-        on the reduction stream (ordered behind the producer by an event) unless VLG_ASYNC_REDUCE=0"""
+        """sum the slabs the producer just launched on the current stream wrote into its arena -> grads[dst_off : +dst_len]:
+        a row of the bucket's table (grouped), or a launch of its own right behind the producer"""
         dst = self.grads.data_ptr() + 4 * dst_off
         if self.group_reduce:
             self._grows.append((self._gcur, stride, n_slabs, dst, dst_len))
             return
-        i = self._arena_turn[kind]
-        arena = self._arenas[kind][i]
-        if not self.async_reduce:
-            call("vlg_reduce_slabs", ptr(arena), stride, n_slabs, dst, dst_len, self._stream())
-            return
-        cur = torch.cuda.current_stream(self.device)
-        e = torch.cuda.Event()
-        e.record(cur)
-        self.reduce_stream.wait_event(e)
-        with torch.cuda.stream(self.reduce_stream):
-            call("vlg_reduce_slabs", ptr(arena), stride, n_slabs, dst, dst_len, self.reduce_stream.cuda_stream)
-            done = torch.cuda.Event()
-            done.record(self.reduce_stream)
-        self._arena_busy[kind][i] = done
-        self._arena_turn[kind] = i ^ 1
-        self._reduce_pending = done
-
-    def _forget_reduce_events(self) -> None:
-        self._arena_busy = {"w": [None, None], "s": [None, None]}
-        self._reduce_pending = None
+        call("vlg_reduce_slabs", ptr(self.slabs_w if kind == "w" else self.slabs), stride, n_slabs, dst, dst_len, self._stream())
 
     def _join_reduces(self) -> None:
-        """the current stream waits for every slab reduction issued so far (they run in order on one stream); grouped
-        reductions: the bucket's one launch is issued here, on the current stream"""
-        if self.group_reduce:
-            if self._grows:
-                key = tuple(self._grows)
-                table = self._gtables.get(key)
-                if table is None:                                   # shapes are static per batch geometry: built once
-                    table = torch.tensor([v for row in key for v in row], dtype=torch.int64, device=self.device)
-                    self._gtables[key] = table
-                call("vlg_reduce_slabs_table", ptr(table), len(key), 128, self._stream())
-                self._grows = []
-            self._goff = 0
+        """grouped reductions: the one launch of the bucket that is complete now, on the current stream (a table of
+        {slabs, stride, count, destination, length} rows in device memory, built once per batch geometry)"""
+        if not self.group_reduce:
             return
-        if self._reduce_pending is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._reduce_pending)
-            self._reduce_pending = None
+        if self._grows:
+            key = tuple(self._grows)
+            table = self._gtables.get(key)
+            if table is None:
+                table = torch.tensor([v for row in key for v in row], dtype=torch.int64, device=self.device)
+                self._gtables[key] = table
+            call("vlg_reduce_slabs_table", ptr(table), len(key), 128, self._stream())
+            self._grows = []
+        self._goff = 0
 
     def _timed(self, family: str, flops: float, name: str, *args, nbytes: float = 0.0) -> None:
         """Launch through the C ABI; when a timer is attached, bracket the launch with events on
@@ -639,11 +602,9 @@ class LayoutEngine:
         self.adam_state.copy_(keep[3]); self.step_count = keep[4]
         self._refresh_shadow()
         timer, self.timer = self.timer, None     # events are not capturable work
-        self._forget_reduce_events()             # (recorded by the eager warm-up step: not part of the capture)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
             self.train_step(static)
-        self._forget_reduce_events()             # (recorded inside the capture: meaningless to a later eager step)
         self.timer = timer
         self.params.copy_(keep[0]); self.exp_avg.copy_(keep[1]); self.exp_avg_sq.copy_(keep[2])
         self.adam_state.copy_(keep[3]); self.step_count = keep[4]
