@@ -249,6 +249,9 @@ int vlg_rollout_input(const float* e_a, const float* seg_a, const float* img_a, 
 #define VLG_CEPI_PRELU  4   /* out = prelu(out)         (activation applied by the producer)     */
 #define VLG_CEPI_DPRELU 8   /* dgrad: din = acc * prelu'(x_in); slope-gradient partials -> da    */
 #define VLG_CEPI_ACCUM  16  /* C += result              (tensor consumed by several blocks)      */
+#define VLG_CEPI_CIN4   32  /* fwd: only input channels 0..3 carry data (the image layers of the frozen trunks, 3 channels in a
+                               32-channel padded tensor): contract over (tap, 4 channels) - same result, 1/6 of the products.
+                               Stride 1, no activation on load, no residual / PReLU epilogue (else VLG_ERR_SHAPE). */
 int vlg_conv3x3_fwd(const float* in, const float* w, const float* bias, float* out, const float* resid,
                     const float* rowmask, const float* prelu_slope, const int* rowtab, int64_t rows_out,
                     int cin_p, int cout, int cout_p, int wp_in, int act_ch, int epilogue,

@@ -272,6 +272,38 @@ def test_tail_split_convs(dev, b, H, W, cin, cout, resid):
     assert not bool(torch.isnan(ws2).all())
 
 
+@pytest.mark.parametrize("b,H,W,cin,cout", [(1, 16, 16, 3, 64), (2, 40, 44, 3, 64), (1, 24, 28, 4, 20)])
+def test_image_layer_conv_cin4(dev, b, H, W, cin, cout):
+    """First layers of the frozen VGG19 / HED trunks (loss.py:29-49, hned.py:9-58: Conv2d(3, 64, 3, padding=1) on the
+    image, no activation in front): VLG_CEPI_CIN4 contracts over (tap, 4 channels) instead of 9 x 32 padded channels -
+    the same convolution, against the same fp64 reference; halo stays zero; a partial row tile and a narrow head."""
+    from vlg import hip
+    from vlg.hip import CEPI_CIN4
+    lib = hip.load()
+    g = torch.Generator().manual_seed(31 * cin + cout + H)
+    h = _Harness(dev, b, H, W, cin, cout, 1)
+    x = torch.randn(b, cin, H, W, generator=g)
+    w = (torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cin * 9) ** 0.5
+    bias = (torch.rand(cout, generator=g) * 2 - 1) * 0.1
+    y_w = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    h.put(x, h.x, cin, h.gi)
+    wdev = h.pack_weight(w)
+    bdev = torch.zeros(h.cout_p, device=dev)
+    bdev[:cout] = bias.to(dev)
+    h.y.buf.fill_(7.0)                                   # stale contents everywhere, guard band included
+    hip.call("vlg_conv3x3_fwd", h.x.ptr, wdev.data_ptr(), bdev.data_ptr(), h.y.ptr, 0, h.go.mask.data_ptr(), 0, 0, h.go.rows,
+             h.cin_p, cout, h.cout_p, h.gi.wp, h.cin_p, CEPI_CIN4, 0, 0, h.S)
+    _rel(h.get(h.y, cout, h.go), y_w, "image-layer forward")
+    yp = h.y.buf[h.go.guard * h.cout_p:(h.go.guard + h.go.rows) * h.cout_p].view(b, H + 2, W + 2, h.cout_p)
+    assert float(yp[:, 0, :, :cout].abs().max()) == 0 and float(yp[:, :, 0, :cout].abs().max()) == 0
+    assert float(yp[:, -1, :, :cout].abs().max()) == 0 and float(yp[:, :, -1, :cout].abs().max()) == 0
+    # combinations the image-layer kernel does not implement are refused on the host
+    zero = torch.zeros(4, device=dev)
+    rc = lib.vlg_conv3x3_fwd(h.x.ptr, wdev.data_ptr(), bdev.data_ptr(), h.y.ptr, 0, h.go.mask.data_ptr(), zero.data_ptr(), 0,
+                             h.go.rows, h.cin_p, cout, h.cout_p, h.gi.wp, h.cin_p, CEPI_CIN4, 0, 0, h.S)
+    assert rc == 1001
+
+
 def test_dgrad_accumulates_into_shared_input(dev):
     """A tensor consumed by two blocks (gridnet.py:51-56) collects both data gradients: VLG_CEPI_ACCUM adds."""
     from vlg import hip

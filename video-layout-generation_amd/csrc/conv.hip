@@ -732,6 +732,96 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     }
 }
 
+// ---- first layers of the frozen trunks (3 image channels in a 32-channel padded tensor): as a 9 x 32-deep implicit GEMM they
+// multiply 29 zero channels per tap (6-8 TFLOP/s algorithmic, 117 us at 4 x 256 x 256).  Here the contraction is over (tap, 4
+// channels): k = 4 * tap + c, 12 tap slots (9 real), K = 48.  A row's tap slot is ONE 16-byte load (channels 0..3 of the
+// shifted pixel) that lands 16-byte aligned in the [rows][48 + 4] LDS tile; the weights are read from the standard
+// [cout][9][cin_p] layout the same way (channels 0..3 of each tap; slots 9..11 are zero).  One K range, no main loop: a block
+// loads its 128 x 48 and 64 x 48 tiles once, runs 24 MFMAs per 32 x 32 output tile and stores; several blocks per CU
+// (40 KB of LDS each) overlap each other's loads.  Output bound: 64 channels x 4 B per pixel.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void conv_first_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                                     const float* __restrict__ rowmask, int M, int lda, int ldb,
+                                                                     int ldc, int N, int wp) {
+    constexpr int BM = 128, BN = 64, KS = 12, LDK = 4 * KS + 4;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = __builtin_amdgcn_readfirstlane(tm * BM), n0 = __builtin_amdgcn_readfirstlane(tn * BN);
+    // Buffer loads: a thread owns tap slot 4g + (tid & 3) of rows tid / 4 and tid / 4 + 64 for g = 0, 1, 2 - its byte offset
+    // (row, tap shift) is one register per g, the tile's first row is the scalar offset.  The descriptor spans the guard band
+    // in front of the tensor and ends behind the last row a tap can reach: rows past M read as zeros, no clamps.  Slots 9..11
+    // (g = 2, tid & 3 != 0) get an offset beyond the descriptor: zeros on both operands.
+    const int pad = wp + 1, t3 = tid & 3, r4 = tid >> 2;
+    const __amdgpu_buffer_rsrc_t dA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in - (int64_t)pad * lda), 0,
+                                                                        (int)(((int64_t)M + 2 * pad) * lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, (int)((int64_t)N * ldb * 4), 0x00020000);
+    v4f xa[6], xb[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int tap = 4 * g + t3;
+        const bool real = tap < 9;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int va = real ? (r4 + (ky - 1) * wp + kx - 1 + pad) * lda * 4 : 0x7ffffff0;
+        const int vb = real ? (r4 * ldb + tap * lda) * 4 : 0x7ffffff0;
+        xa[2 * g] = __builtin_amdgcn_raw_buffer_load_b128(dA, va, m0 * lda * 4, 0);
+        xa[2 * g + 1] = __builtin_amdgcn_raw_buffer_load_b128(dA, va, (m0 + 64) * lda * 4, 0);
+        xb[g] = __builtin_amdgcn_raw_buffer_load_b128(dB, vb, n0 * ldb * 4, 0);
+    }
+    // epilogue operands fetched now, behind the tile loads: the halo mask of this lane's 32 rows, the bias of its column
+    const int wm = wave >> 1, wn = wave & 1;                   // 2 x 2 waves: 64 rows x 32 columns each
+    const __amdgpu_buffer_rsrc_t dMk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowmask ? rowmask : in), 0, rowmask ? M * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dBi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias ? bias : in), 0, bias ? N * 4 : 0, 0x00020000);
+    float mk[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            mk[i][r] = rowmask ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dMk, (wm * 64 + 4 * h) * 4, (m0 + i * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0)) : 1.0f;
+    const float bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dBi, (wn * 32 + l31) * 4, n0 * 4, 0));
+    float* const aw = As + r4 * LDK + 4 * t3;
+    float* const bw = Bs + r4 * LDK + 4 * t3;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        *reinterpret_cast<v4f*>(aw + 16 * g) = xa[2 * g];
+        *reinterpret_cast<v4f*>(aw + 64 * LDK + 16 * g) = xa[2 * g + 1];
+        *reinterpret_cast<v4f*>(bw + 16 * g) = xb[g];
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const float* const ar = As + (wm * 64 + l31) * LDK + 4 * h;
+    const float* const br = Bs + (wn * 32 + l31) * LDK + 4 * h;
+#pragma unroll
+    for (int sc = 0; sc < 4 * KS / 8; ++sc) {
+        const float4 b = ld4(br + 8 * sc);
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 a = ld4(ar + i * 32 * LDK + 8 * sc);
+            const float aa[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[kk], bb[kk], acc[i], 0, 0, 0);
+        }
+    }
+    // stores through a descriptor that ends with row M and (per row) is entered only by columns < N: a lane of a column past
+    // N takes an offset beyond it, rows past M fall off its end - dropped by the hardware
+    const __amdgpu_buffer_rsrc_t dC = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((int64_t)M * ldc * 4), 0x00020000);
+    const int vc = n0 + wn * 32 + l31 < N ? ((wm * 64 + 4 * h) * ldc + wn * 32 + l31) * 4 : 0x7ffffff0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = (acc[i][r] + bv) * mk[i][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dC, vc, ((m0 + i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + n0) * 4, 0);
+        }
+}
+
 template <int MODE, int BM, int BN, int BK = 32>
 static int launch_conv(ConvArgs g, hipStream_t s) {
     g.tiles_m = (int)((g.M + BM - 1) / BM);
@@ -922,9 +1012,19 @@ extern "C" int vlg_conv3x3_fwd(const float* in, const float* w, const float* bia
     g.rowtab = rowtab; g.tab_stride = 0;
     g.M = rows_out; g.N = cout; g.Kc = 9 * (int64_t)cin_p;
     g.lda = cin_p; g.ldb = 9 * cin_p; g.ldc = cout_p; g.cin = cin_p;
-    g.splits = 1; g.kc_per_split = g.Kc; g.epi = epilogue & ~VLG_CEPI_DPRELU; g.act_ch = act_ch;
+    g.splits = 1; g.kc_per_split = g.Kc; g.epi = epilogue & ~(VLG_CEPI_DPRELU | VLG_CEPI_CIN4); g.act_ch = act_ch;
     fill_shifts(g, wp_in, rowtab ? 1 : 1);
     hipStream_t s = (hipStream_t)stream;
+    if (epilogue & VLG_CEPI_CIN4) {                            // image-channel first layer: contraction over (tap, 4 channels)
+        if (rowtab != nullptr || prelu_slope != nullptr || (epilogue & (VLG_CEPI_RESID | VLG_CEPI_PRELU)) || wp_in < 1) return VLG_ERR_SHAPE;
+        const int64_t blocks = ((rows_out + 127) / 128) * ((cout + 63) / 64);
+        // (32-bit byte offsets inside the kernel's buffer descriptors)
+        if (blocks > 0x7fffffff || (rows_out + 2 * (int64_t)(wp_in + 1) + 128) * cin_p * 4 >= (1ll << 31) ||
+            (rows_out + 128) * (int64_t)cout_p * 4 >= (1ll << 31)) return VLG_ERR_SHAPE;
+        hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, s, in, w, bias, out, rowmask, (int)rows_out,
+                           cin_p, 9 * cin_p, cout_p, cout, wp_in);
+        return vlg_last_error();
+    }
     const int splits = workspace != nullptr ? conv_fwd_splits(rows_out, cin_p, cout, cout_p) : 1;
     if (splits > 1) {
         if (!vlg_aligned16(workspace) || (epilogue & VLG_CEPI_PRELU)) return VLG_ERR_ALIGN;

@@ -84,7 +84,7 @@ SIGNATURES = {
     "vlg_add_rows": (I, [P, P, L, I, P]),
     "vlg_sum_partials": (I, [P, I, P, I, P]),
 }
-CEPI_BIAS, CEPI_RESID, CEPI_PRELU, CEPI_DPRELU, CEPI_ACCUM = 1, 2, 4, 8, 16
+CEPI_BIAS, CEPI_RESID, CEPI_PRELU, CEPI_DPRELU, CEPI_ACCUM, CEPI_CIN4 = 1, 2, 4, 8, 16, 32
 
 _lib = None
 

@@ -20,7 +20,7 @@ import torch
 
 from . import hip
 from .gridnet import _Geo, _PT
-from .hip import call, ptr
+from .hip import CEPI_CIN4, call, ptr
 
 STAGES = (("moduleVggOne", 3, 64, (0, 2)), ("moduleVggTwo", 64, 128, (1, 3)), ("moduleVggThr", 128, 256, (1, 3, 5)),
           ("moduleVggFou", 256, 512, (1, 3, 5)), ("moduleVggFiv", 512, 512, (1, 3, 5)))
@@ -130,7 +130,8 @@ class HNEDHIP:
                 done_pool.add(si)
             g = tout.geo
             call("vlg_conv3x3_fwd", tin.ptr, self._pp(key + ".weight"), self._pp(key + ".bias"), tout.ptr, 0, ptr(g.mask),
-                 self._pp("_zero") if relu else 0, 0, g.rows, tin.cp, cout, tout.cp, g.wp, tin.cp, 0, ptr(self.ws), self.ws_n, s)
+                 self._pp("_zero") if relu else 0, 0, g.rows, tin.cp, cout, tout.cp, g.wp, tin.cp,
+                 CEPI_CIN4 if (cin <= 4 and not relu) else 0, ptr(self.ws), self.ws_n, s)
         for k, (name, f) in enumerate(zip(SCORES, self.feats)):
             call("vlg_score1x1_relu", f.ptr, self._pp(name + ".weight"), self._pp(name + ".bias"), ptr(self.score[k]), b,
                  f.geo.H, f.geo.W, f.C, f.cp, s)

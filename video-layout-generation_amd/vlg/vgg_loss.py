@@ -21,7 +21,7 @@ import torch
 
 from . import hip
 from .gridnet import _Geo, _PT
-from .hip import CEPI_DPRELU, call, ptr
+from .hip import CEPI_CIN4, CEPI_DPRELU, call, ptr
 
 CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512)     # torchvision vgg19 cfg 'E', first 27 modules
 
@@ -128,8 +128,10 @@ class VggLossHIP:
             else:
                 _, key, tin, tout, ci, co, relu = op
                 g = tout.geo
+                # (the image layer: 3 channels in a 32-channel padded tensor - contraction over (tap, 4 channels))
                 call("vlg_conv3x3_fwd", tin.ptr, self._pp(key + ".weight"), self._pp(key + ".bias"), tout.ptr, 0, ptr(g.mask),
-                     self._pp("_zero") if relu else 0, 0, g.rows, tin.cp, co, tout.cp, g.wp, tin.cp, 0, ptr(self.ws), self.ws_n, s)
+                     self._pp("_zero") if relu else 0, 0, g.rows, tin.cp, co, tout.cp, g.wp, tin.cp,
+                     CEPI_CIN4 if (ci <= 4 and not relu) else 0, ptr(self.ws), self.ws_n, s)
 
     def loss_and_grad(self, output: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0, want_grad: bool = True):
         """Returns (loss[1] device tensor, d(grad_scale * loss)/d output as (b,3,H,W) or None)."""
