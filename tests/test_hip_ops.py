@@ -298,7 +298,7 @@ def test_linear_dgrad_wgrad(H, dev, M, N, K):
 
 
 # ------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("T,d,n_seq", [(4, 64, 5), (8, 128, 3), (16, 256, 6), (32, 256, 3), (16, 512, 2)])
+@pytest.mark.parametrize("T,d,n_seq", [(4, 64, 5), (8, 128, 3), (16, 256, 6), (32, 256, 3), (16, 512, 2), (32, 512, 5), (32, 64, 7)])
 def test_attention_fwd_bwd(H, dev, T, d, n_seq):
     torch.manual_seed(5)
     Hn = d // 64
