@@ -47,6 +47,7 @@ struct ConvArgs {
     int tail_tiles, tail_splits;
     int64_t tail_kc, tail_row0, tail_stride;
     float* tail_ws;
+    unsigned long long* probe;   // diagnostic build only (-DVLG_TIMELINE, tools/diag/conv_timeline.py)
 };
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
@@ -83,6 +84,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     float* const Bs0 = smem + 2 * TA::FLOATS;
 
     const int bid = blockIdx.x;
+#ifdef VLG_TIMELINE
+    const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+    unsigned long long tl_loop0 = 0, tl_loop1 = 0, tl_vm = 0, tl_bar = 0, tl_c0 = 0, tl_c1 = 0;
+#endif
     const int ntile = g.tiles_m * g.tiles_n;
     // The K ranges of the tail tiles come FIRST in launch order (padded to a multiple of 8 blocks so that the whole tiles
     // behind them keep block % 8 = XCD): an empty chip deals them one per CU, next to a whole tile each.  Put last, they
@@ -321,6 +326,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             }
         }
     };
+#ifdef VLG_TIMELINE
+    tl_loop0 = __builtin_amdgcn_s_memrealtime();
+    tl_c0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- fast path (forward / data gradient of a stride-1 convolution with one slope for every staged channel): the main
     // loop of gemm.hip's fast path - NO vector-ALU instruction for addresses.  v_mfma_f32_32x32x2_f32 and the vector ALU of
     // a SIMD execute serially (tools/micro/mfma_f32_valu_share.hip): the general loop above spends 60-140 vector instructions
@@ -385,6 +394,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             const float sel = slope <= 1.0f ? __builtin_inff() : -__builtin_inff();
             const v2f slope2 = v2(slope);
             auto store = [&](int c, auto act_tag) __attribute__((always_inline)) {
+#ifdef VLG_TIMELINE
+                {   // time this wave spends waiting for its tile loads
+                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    tl_vm += __builtin_amdgcn_s_memtime() - w0;
+                }
+#endif
                 if constexpr (decltype(act_tag)::value) {
 #pragma unroll
                     for (int i = 0; i < TA::NV; ++i) {
@@ -413,7 +429,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
                 for (int sch = 0; sch < NCH; ++sch) {
                     if (sch + 1 < NCH) ldf(fa[(sch + 1) & 1], fb[(sch + 1) & 1], cur, sch + 1);
                     if (sch == NCH - 1) {
+#ifdef VLG_TIMELINE
+                        const unsigned long long b0 = __builtin_amdgcn_s_memtime();
                         __syncthreads();
+                        tl_bar += __builtin_amdgcn_s_memtime() - b0;
+#else
+                        __syncthreads();
+#endif
                         ldf(fa[0], fb[0], cur ^ 1, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -581,6 +603,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
     }
     }
     __syncthreads();
+#ifdef VLG_TIMELINE
+    tl_loop1 = __builtin_amdgcn_s_memrealtime();
+    tl_c1 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h)
     // (a K range of a tail tile stores its raw partial sums: rows are addressed as in the full tensor, so the base is moved back)
@@ -730,6 +756,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             if (tid == 0) g.da_slab[bid] = da;
         }
     }
+#ifdef VLG_TIMELINE
+    if (g.probe) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tl_exit = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* o = g.probe + 8 * (size_t)bid;
+            o[0] = tl_entry; o[1] = tl_loop0; o[2] = tl_loop1; o[3] = tl_exit;
+            o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));        // HW_REG_HW_ID
+            o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));       // HW_REG_XCC_ID
+            o[6] = (unsigned long long)tile;
+            o[7] = ((tl_c1 - tl_c0) << 40) | ((tl_vm & 0xfffff) << 20) | (tl_bar & 0xfffff);   // shader clocks: loop | load waits | barrier waits (wave 0)
+        }
+    }
+#endif
 }
 
 // ---- first layers of the frozen trunks (3 image channels in a 32-channel padded tensor): as a 9 x 32-deep implicit GEMM they
@@ -822,8 +862,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_first_kernel(const float
         }
 }
 
+#ifdef VLG_TIMELINE
+static unsigned long long* vlg_conv_probe = nullptr;
+extern "C" void vlg_debug_set_conv_probe(unsigned long long* p) { vlg_conv_probe = p; }
+#endif
 template <int MODE, int BM, int BN, int BK = 32>
 static int launch_conv(ConvArgs g, hipStream_t s) {
+#ifdef VLG_TIMELINE
+    g.probe = vlg_conv_probe;
+#endif
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (g.N + BN - 1) / BN;
     const int64_t blocks = g.tail_tiles > 0 ? (int64_t)g.tiles_m * g.tiles_n - g.tail_tiles + (((int64_t)g.tail_tiles * g.tail_splits + 7) & ~7ll)
