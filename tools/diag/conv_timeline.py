@@ -3,7 +3,7 @@
 
     cd video-layout-generation_amd/csrc && hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DVLG_TIMELINE -c conv.hip -o /tmp/conv_tl.o && \
         hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libvlg_tl.so /tmp/conv_tl.o $(ls *.o | grep -v '^conv.o')
-    VLG_HIP_LIB=$PWD/tools/ab/libvlg_tl.so python tools/diag/conv_timeline.py [hw cin cout [batch]]
+    VLG_HIP_LIB=$PWD/tools/ab/libvlg_tl.so python tools/diag/conv_timeline.py [hw cin cout [batch [fwd|dgrad|wgrad]]]
 
 Every block stamps s_memrealtime (100 MHz) at entry, main-loop start, main-loop end and exit (stores drained) with
 HW_ID / XCC_ID: block lifetime, prologue / loop / epilogue split, blocks per CU over time, idle gaps per CU."""
@@ -17,6 +17,7 @@ from vlg.gridnet import _Geo, _PT
 
 hw, cin, cout = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 32, 32)
 b = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+mode = sys.argv[5] if len(sys.argv) > 5 else "fwd"          # fwd | dgrad | wgrad
 dev = torch.device("cuda:0")
 lib = hip.load()
 raw = ctypes.CDLL(hip.LIB_PATH)
@@ -29,8 +30,18 @@ x.buf.normal_()
 w = torch.randn(y.cp * 9 * x.cp, device=dev) * 0.05
 bias = torch.zeros(y.cp, device=dev)
 zero = torch.zeros(4, device=dev)
-run = lambda: call("vlg_conv3x3_fwd", x.ptr, ptr(w), ptr(bias), y.ptr, 0, ptr(geo.mask), ptr(zero), 0, geo.rows, x.cp, cout, y.cp,
-                   geo.wp, x.cp, 0, 0, 0, S)
+y.buf.normal_()
+dx = _PT(geo, cin, dev, False)
+da = torch.zeros(lib.vlg_conv3x3_dgrad_slabs(geo.rows, x.cp) + 8, device=dev)
+n_slab = lib.vlg_conv3x3_wgrad_slabs(geo.rows, x.cp, y.cp)
+slab_stride = y.cp * 9 * x.cp + y.cp
+slabs = torch.empty(n_slab * slab_stride, device=dev)
+run = {"fwd": lambda: call("vlg_conv3x3_fwd", x.ptr, ptr(w), ptr(bias), y.ptr, 0, ptr(geo.mask), ptr(zero), 0, geo.rows, x.cp, cout, y.cp,
+                           geo.wp, x.cp, 0, 0, 0, S),
+       "dgrad": lambda: call("vlg_conv3x3_dgrad", y.ptr, ptr(w), dx.ptr, x.ptr, ptr(geo.mask), ptr(zero), ptr(da), 0, 0, geo.rows, x.cp, y.cp,
+                             geo.wp, x.cp, 8, 0, 0, da.numel(), S),
+       "wgrad": lambda: call("vlg_conv3x3_wgrad", y.ptr, x.ptr, ptr(slabs), slab_stride, slabs.numel(), 0, ptr(zero), geo.rows, x.cp, y.cp,
+                             geo.wp, x.cp, S)}[mode]
 nblk = 1 << 16
 probe = torch.zeros(8 * nblk, dtype=torch.int64, device=dev)
 for _ in range(3000):

@@ -523,6 +523,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
             const float sel = slope <= 1.0f ? __builtin_inff() : -__builtin_inff();
             const v2f slope2 = v2(slope);
             auto store = [&](int c, auto act_tag) __attribute__((always_inline)) {
+#ifdef VLG_TIMELINE
+                {
+                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    tl_vm += __builtin_amdgcn_s_memtime() - w0;
+                }
+#endif
 #pragma unroll
                 for (int i = 0; i < TA::NV; ++i) {
                     const v2f lo = __builtin_shufflevector(xa[i], xa[i], 0, 1), hi = __builtin_shufflevector(xa[i], xa[i], 2, 3);
@@ -556,7 +563,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_kernel(const ConvAr
                 for (int sch = 0; sch < NCH; ++sch) {
                     if (sch + 1 < NCH) ldf(fa[(sch + 1) & 1], fb[(sch + 1) & 1], cur, sch + 1);
                     if (sch == NCH - 1) {
+#ifdef VLG_TIMELINE
+                        const unsigned long long b0 = __builtin_amdgcn_s_memtime();
                         __syncthreads();
+                        tl_bar += __builtin_amdgcn_s_memtime() - b0;
+#else
+                        __syncthreads();
+#endif
                         ldf(fa[0], fb[0], cur ^ 1, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
