@@ -98,7 +98,7 @@ def test_embed_class_table_matches_reference_embedding(H, dev):
 
 
 # ----------------------------------------------------------------------- layer-norm
-@pytest.mark.parametrize("rows,d", [(7, 64), (1000, 256), (513, 512), (64, 128), (40, 1024)])
+@pytest.mark.parametrize("rows,d", [(7, 64), (1000, 256), (1003, 256), (513, 512), (64, 128), (40, 1024), (3, 192)])
 def test_layernorm_fwd_bwd(H, dev, rows, d):
     torch.manual_seed(1)
     x = (torch.randn(rows, d) * 2 + 0.5).requires_grad_(True)
