@@ -21,11 +21,25 @@ Objects on the line besides the contract's fields:
   cpu_baseline    the CPU oracle's identical step (torch-CPU, host threads stated) on a bounded sample of the SAME batch
   bf16_projections / f32x3_projections   the two other projection modes (informational; `value` stays native fp32)
   strong_scaling_shard   the per-GPU share of the reference's GLOBAL batch semantics (src/trainer.py:148: 32 // 8 = 4 clips)
+  comm            (N > 1, or the forced world-1 leg) backend, world size as torch.distributed reports it, the device index of
+                  every rank (all-gathered), bytes all-reduced per step, and exposed_comm_ms = ms/step with the bucketed
+                  reducer - ms/step of the same ranks with reducer=None (both MAX over ranks)
+  rccl_world1     (N = 1) the same step with a real RCCL communicator of world size 1 and the six bucket all-reduces issued
+  reference_step  the step that EXISTS in the reference (src/trainer.py:193-258: CoordGridNet + HED x2 + L1/GD/SSIM/VGG/CE +
+                  Adam at 256x256), b = 4 and b = 32: ms/step, samples/s, algorithmic TFLOP/s, the event-timed roofline of its
+                  dominant convolution shape, and a bounded CPU baseline of its restatement (oracle/image_step_spec.py)
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks ITSELF (the reference's launcher is one
+command too: src/main.py:183-185 mp.spawn): the parent - before any HIP call - runs `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line and exits with the child's status.
 """
 import argparse
+import contextlib
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -125,6 +139,172 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n: int) -> "int":
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as children of THIS process, which has
+    made no HIP call (importing torch does not initialise the device), relay rank 0's JSON line, return the children's status.
+    Never an exec: a process is started, not replaced."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, VLG_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return r.returncode if (r.returncode != 0 or lines) else 1
+
+
+def rccl_world1_leg(cfg, dev, batch, steps: int):
+    """N = 1 only, informational: the SAME step with a real RCCL communicator (world size 1) and the six bucket all-reduces
+    + split Adam really issued (GradReducer(always_communicate=True)) - the data-parallel code path on the one GPU there is."""
+    import torch.distributed as dist
+    from vlg.dp import GradReducer, bucket_ranges
+    from vlg.engine import LayoutEngine
+    from vlg.spec import SEED
+    try:
+        with _StdoutToStderr():
+            dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % free_port(), world_size=1, rank=0, device_id=dev)
+            dist.all_reduce(torch.zeros(4, device=dev))
+            torch.cuda.synchronize()
+        e5 = LayoutEngine(cfg, dev, seed=SEED)
+        red = GradReducer(e5.grads_ext, bucket_ranges(e5.layout, e5.n_params, cfg.n_layers), always_communicate=True)
+        for _ in range(3):
+            e5.train_step(batch, red)
+        with _StdoutToStderr():
+            with_comm = timed_steps(lambda: e5.train_step(batch, red), steps)
+        without = timed_steps(lambda: e5.train_step(batch, None), steps)
+        out = {"backend": dist.get_backend() + " (RCCL)", "world": dist.get_world_size(), "ms_per_step": round(1e3 * with_comm, 4),
+               "ms_per_step_no_reducer": round(1e3 * without, 4), "exposed_comm_ms": round(1e3 * (with_comm - without), 4),
+               "bytes_allreduced_per_step": 4 * int(e5.grads_ext.numel()), "buckets": len(red.buckets),
+               "final_loss": round(float(e5.loss_out[0]), 5),
+               "note": "one process, RCCL communicator of world size 1: six asynchronous bucket all-reduces + split Adam issued every step"}
+        del e5
+        dist.destroy_process_group()
+        return out
+    except Exception as ex:                              # informational leg: never costs the line
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+
+REFERENCE_GFLOP_PER_SAMPLE = 188.7 + 2 * 40.1 + 3 * 46.1      # SURVEY.md section 6 / 8d Spec R: GridNet fwd+bwd, HED x2, VGG19[:27] x2 fwd + dgrad
+
+
+class _ConvTimer:
+    """hip.tracer hook: brackets every vlg_conv3x3_{fwd,dgrad,wgrad} launch with events on the launch stream, grouped by
+    (entry point, padded rows, input channels, output channels)."""
+    ARGS = {"vlg_conv3x3_fwd": (8, 9, 10), "vlg_conv3x3_dgrad": (9, 10, 11), "vlg_conv3x3_wgrad": (7, 8, 9)}    # rows, cin_p, cout(_p)
+
+    def __init__(self):
+        self.rec = {}
+
+    def __call__(self, name, args):
+        if name not in self.ARGS:
+            return None
+        key = (name,) + tuple(int(args[i]) for i in self.ARGS[name])
+        return self._section(key)
+
+    @contextlib.contextmanager
+    def _section(self, key):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        yield
+        e.record()
+        self.rec.setdefault(key, []).append((s, e))
+
+
+def reference_step_leg(dev, cpu: bool = True):
+    """The step that exists in the reference (src/trainer.py:193-258), driver-timed: CoordGridNet + frozen HED x2 + 40 L1 +
+    20 (VGG + GradientLoss + SSIM) + 10 CE + Adam on 256x256 frames, b = 4 and b = 32 (the reference's default batch), with
+    torch-default random weights (the trained HED / VGG weights are not in the reference repository)."""
+    from vlg import hip
+    from vlg.image_engine import ImageEngine, random_state, synthetic_frames
+    H = W = 256
+    out = {"gflop_per_sample": round(REFERENCE_GFLOP_PER_SAMPLE, 1), "frames": "%dx%d" % (H, W),
+           "step": "src/trainer.py:193-258 with the Appendix-A repairs: prep -> CoordGridNet -> 40 L1 + 20 (VGG + GD + SSIM) + 10 CE "
+                   "-> backward -> Adam; HED fused map x2 under no-grad"}
+    for b in (4, 32):
+        eng = ImageEngine(b, H, W, dev, arch="CoordGridNet", with_hed=True, with_vgg=True)
+        eng.load_state_dict(random_state(eng.net.reference_shapes(), 1024))
+        eng.hed.load_state_dict(random_state(eng.hed.reference_shapes(), 1041))
+        eng.vgg.load_state_dict(random_state(eng.vgg.reference_shapes(), 1042))
+        batch = {k: v.to(dev) for k, v in synthetic_frames(b, H, W, seed=1024).items() if k not in ("e1", "e2")}
+        for _ in range(3):
+            eng.train_step(batch)
+        dt = timed_steps(lambda: eng.train_step(batch), 10)
+        rec = {"ms_per_step": round(1e3 * dt, 3), "samples_per_s": round(b / dt, 1),
+               "algorithmic_tflops": round(b * REFERENCE_GFLOP_PER_SAMPLE / dt / 1e3, 1),
+               "frac_of_fp32_mfma_peak": round(b * REFERENCE_GFLOP_PER_SAMPLE / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+               "loss": round(float(eng.total()), 5)}
+        ct = _ConvTimer()                                   # untimed pass: every convolution launch bracketed
+        hip.tracer = ct
+        try:
+            eng.train_step(batch)
+            eng.train_step(batch)
+            torch.cuda.synchronize()
+        finally:
+            hip.tracer = None
+        groups = []
+        for (name, rows, cin, cout), ev in ct.rec.items():
+            ms = [s.elapsed_time(e) for s, e in ev]
+            groups.append((sum(ms), name, rows, cin, cout, len(ms) // 2, sum(ms) / len(ms)))
+        total_conv = sum(g[0] for g in groups) / 2
+        groups.sort(reverse=True)
+        # the dominant convolution shape.  `rows` counts the halo-padded pixels of the level; the algorithmic work is over the
+        # b * h * w real ones (level h x w from rows = b (h + 2)(w + 2), square levels) and the real channel counts - equal to
+        # the padded ones from 32 channels up, which every shape that can lead this list has.
+        tot, name, rows, cin, cout, launches, avg_ms = groups[0]
+        side = int(round((rows / b) ** 0.5)) - 2
+        gflop = 2.0 * b * side * side * 9 * cin * cout / 1e9
+        rec["conv_ms_per_step"] = round(total_conv, 3)
+        rec["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_kernel via %s, %d->%d channels at %dx%dx%d" % (name, cin, cout, b, side, side),
+                           "launches_per_step": launches, "avg_launch_us": round(1e3 * avg_ms, 2), "gflop_per_launch": round(gflop, 3),
+                           "achieved": round(gflop / avg_ms, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(gflop / avg_ms / PEAK_F32_MFMA_TFLOPS, 4), "share_of_step": round(tot / 2 / (1e3 * dt), 4)}
+        out["b%d" % b] = rec
+        del eng, batch
+        torch.cuda.empty_cache()
+    if cpu:
+        out["cpu_baseline"] = reference_cpu_baseline()
+    return out
+
+
+def reference_cpu_baseline():
+    """The torch-CPU restatement of the same step (oracle/image_step_spec.py + hned_spec + vgg_spec; the reference's own
+    trainer cannot be imported: SURVEY.md section 8c), one sample per step, bounded."""
+    from oracle import gridnet_spec as G, hned_spec as HS, image_step_spec as S, vgg_spec as V
+    from vlg.image_engine import synthetic_frames
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(threads)
+    p = G.test_params(G.param_shapes(10, coord=True), seed=0)
+    hp, vp = HS.test_params(0), V.test_params(0)
+    batch = synthetic_frames(1, 256, 256, seed=1024)
+
+    def step():
+        with torch.no_grad():
+            batch["e1"] = HS.forward(hp, batch["frame1"])[5]
+            batch["e2"] = HS.forward(hp, batch["frame2"])[5]
+        S.loss_and_grads(p, batch, True, vgg_params=vp)
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 and time.perf_counter() - t0 < 15.0:
+        step()
+        n += 1
+    el = time.perf_counter() - t0
+    return {"value": round(n / el, 3), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of 1 sample (256x256), torch-CPU restatement fwd+bwd without Adam, %.1f s" % (n, el)}
+
+
 def timed_steps(step_fn, n: int) -> float:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -152,8 +332,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (other modes, B=4 shard)")
+    ap.add_argument("--no-reference-step", action="store_true", help="skip the reference's own pixel step (reference_step object)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -248,6 +431,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = [float(x) / world for x in eng.loss_out.cpu()]     # summed over ranks inside the first bucket
+    comm = None
+    if reducer is not None:
+        # communication evidence: who took part, what moved, and what it cost on top of the same ranks' compute
+        eng.timer = None
+        for _ in range(2):
+            eng.train_step(batch, None)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.train_step(batch, None)
+        sync_all()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_no_comm = 1e3 * float(t.item()) / args.steps
+        prop = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "name": prop.name,
+                "pci": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0), getattr(prop, "pci_device_id", 0))}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        comm = {"backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""),
+                "world": dist.get_world_size(), "ranks": seen,
+                "bytes_allreduced_per_step": 4 * int(eng.grads_ext.numel()), "buckets": len(reducer.buckets),
+                "ms_per_step_no_reducer": round(ms_no_comm, 4),
+                "exposed_comm_ms": round(1e3 * elapsed / args.steps - ms_no_comm, 4),
+                "note": "bucketed async all-reduce (SUM) of the flat gradient + 4 loss floats, 1/world folded into Adam; "
+                        "exposed = with reducer - reducer=None on the same ranks, both MAX over ranks"}
+        eng.timer = ktimer
 
     if rank == 0:
         clips = world * cfg.B * args.steps
@@ -267,6 +477,7 @@ def main():
                        "step_tflops": round(fl["fwd_bwd"] * args.steps / elapsed / 1e12, 2),
                        "final_loss": [round(x, 5) for x in loss]},
         }
+        line["comm"] = comm
         roof, roof_hbm = None, None
         if eng.timer is not None:
             s = eng.timer.summary()[DOMINANT]
@@ -387,6 +598,10 @@ def main():
                 "note": "one rank's share if the GLOBAL batch stayed 32 on 8 GPUs (reference semantics); no communication here: "
                         "the 12.7 MB gradient all-reduce would have to hide inside this step time"}
             del e4
+            if not distributed:
+                line["rccl_world1"] = rccl_world1_leg(cfg, dev, batch, args.steps)
+            if not args.no_reference_step:
+                line["reference_step"] = reference_step_leg(dev, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         else:

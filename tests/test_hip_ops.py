@@ -34,7 +34,9 @@ def reduce_slabs(H, slabs, stride, n, length, dev):
 
 
 # ------------------------------------------------------------------------ embedding
-@pytest.mark.parametrize("B,T,N,d", [(2, 4, 8, 64), (3, 16, 5, 256), (2, 32, 4, 512)])
+@pytest.mark.parametrize("B,T,N,d", [(2, 4, 8, 64), (3, 16, 5, 256), (2, 32, 4, 512),
+                                     # widths whose d/4-lane groups straddle 64-lane waves: 48, 96, 80, 112 lanes
+                                     (3, 16, 7, 192), (2, 16, 9, 384), (2, 8, 6, 320), (2, 4, 5, 448), (5, 32, 3, 64)])
 def test_embed_fwd_bwd(H, dev, B, T, N, d):
     torch.manual_seed(0)
     vocab = 21

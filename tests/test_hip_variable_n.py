@@ -82,3 +82,19 @@ def test_pinned_prefetch_delivers_the_same_batches(dev, bucketed):
         for k in BATCH_KEYS:
             assert g[k].is_cuda and g[k].is_contiguous() and g[k].shape == w[k].shape
             assert torch.equal(g[k], w[k]) and torch.equal(g[k].cpu(), r[k]), k
+
+
+def test_prefetched_batches_alias_three_slots(dev):
+    """The lifetime contract of vlg.data.device_prefetch: a yielded batch aliases one of three rotating
+    device slots, so a batch HELD across more than two iterations is overwritten - and prefetch=False hands out fresh
+    tensors that are not."""
+    from vlg.data import ClipLoader, synthetic_clips
+    clips = synthetic_clips(64, T=4, N=8, seed=5)
+    kw = dict(batch=4, seed=9, shuffle=False)
+    held = list(ClipLoader(clips, device=dev, prefetch=True, **kw))[:4]
+    torch.cuda.synchronize()
+    fresh = list(ClipLoader(clips, device=dev, prefetch=False, **kw))[:4]
+    assert held[0]["slot_box"].data_ptr() == held[3]["slot_box"].data_ptr()        # slot 0 reused by batch 3
+    assert len({b["slot_box"].data_ptr() for b in held[:3]}) == 3
+    assert not torch.equal(held[0]["slot_box"], fresh[0]["slot_box"])               # ... and its contents are gone
+    assert len({b["slot_box"].data_ptr() for b in fresh}) == 4

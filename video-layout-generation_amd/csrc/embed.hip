@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     const int wl = threadIdx.x & 63;
     const int tl = lpr >= 64 ? wl : q;                    // this lane's frame slot
     const int lane0 = wl - tl;                            // first lane of the id holders
-    const bool shuffled = lpr >= TT;                      // (d = 64 with T = 32: direct loads)
+    // shuffles only when a group's lanes never straddle a wave (lpr divides 64, or is a multiple of it): at d = 192 / 320 /
+    // 384 / 448 a wave mixes two groups (and their trip counts), so those widths - and d = 64 with T = 32 - load directly
+    const bool shuffled = lpr >= TT && (lpr < 64 ? (64 % lpr) == 0 : (lpr & 63) == 0);
     if (live) {
         for (int64_t seq = (int64_t)blockIdx.x * G + grp; seq < n_seq; seq += (int64_t)gridDim.x * G) {
             const int64_t b = seq / N;

@@ -264,8 +264,11 @@ class Trainer:
 
     def __init__(self, args, engine_factory: Optional[Callable] = None):
         args.logger.info("Initializing trainer")
-        if not os.path.isdir("../predict"):                     # reference src/trainer.py:107-108
-            os.makedirs("../predict", exist_ok=True)
+        # reference src/trainer.py:107-108 creates ../predict relative to the working directory (src/); the default is kept,
+        # args.predict_dir / VLG_PREDICT_DIR move it (tests, read-only working directories)
+        self.predict_dir = str(getattr(args, "predict_dir", None) or os.environ.get("VLG_PREDICT_DIR") or "../predict")
+        if not os.path.isdir(self.predict_dir):
+            os.makedirs(self.predict_dir, exist_ok=True)
         self.args = args
         self.world = max(int(getattr(args, "gpus", 1) or 1), 1)
         self.distributed = dist.is_available() and dist.is_initialized() and self.world > 1
@@ -462,9 +465,9 @@ class Trainer:
             p, q = self.engine.rollout(*inputs, steps=steps)
             p, q = p.cpu().numpy(), q.cpu().numpy()
             t = time()
-            os.makedirs("../predict", exist_ok=True)
-            np.save("../predict/val_" + str(t) + "_img.npy", p)                   # trainer.py:474-476
-            np.save("../predict/val_" + str(t) + "_seg.npy", q)
+            os.makedirs(self.predict_dir, exist_ok=True)
+            np.save(os.path.join(self.predict_dir, "val_" + str(t) + "_img.npy"), p)     # trainer.py:474-476
+            np.save(os.path.join(self.predict_dir, "val_" + str(t) + "_seg.npy"), q)
             return p, q
         if len(inputs) != 2:
             raise TypeError("generate_sequence(slot_class, slot_box) in layout mode")
@@ -491,10 +494,12 @@ class Trainer:
         files, resize the maps to 256 x 256 nearest-neighbour (:439-440; cv2.INTER_NEAREST index rule, vlg/cityscapes.py),
         ToTensor + ImageNet-normalise the frames (:443-447), then generate_sequence.  PIL decodes the files (cv2 is not
         installed here).  An unreadable path logs and returns like :436-438.  A layout-token model has no pixel
-        inputs: there the method raises instead of pretending a path was missing."""
+        inputs: there the method logs an error and returns None, so that `main.py --img1 ...` (main.py:64-67) ends the
+        way the reference's entry does for unusable inputs - a log line, not a traceback."""
         if not self.image_mode:
-            raise NotImplementedError("eval_generate_sequence reads image files: run with VLG_MODEL=gridnet "
-                                      "(layout mode rolls out with generate_sequence(slot_class, slot_box))")
+            self.args.logger.error("eval_generate_sequence reads image files: run with VLG_MODEL=gridnet "
+                                   "(layout mode rolls out with generate_sequence(slot_class, slot_box))")
+            return None
         from vlg.cityscapes import _load_rgb, _load_seg
         from vlg.spec import IMG_MEAN, IMG_STD
         for pth in (img1, img2, seg1, seg2):

@@ -83,11 +83,14 @@ def resize_nearest_cv2(a: np.ndarray, size: Tuple[int, int]) -> np.ndarray:
     """cv2.resize(a, dsize, interpolation=cv2.INTER_NEAREST) (reference src/folder.py:133, src/trainer.py:439-440) by its
     published index rule - destination pixel (y, x) takes source (min(floor(y * H/h), H-1), min(floor(x * W/w), W-1)) -
     which is NOT PIL's NEAREST (that samples at pixel centres, floor((x + 0.5) * W/w)).  cv2 is absent here, so this
-    restatement is unpinned against cv2 itself; an 8x downscale picks rows 0, 8, 16 ... as OpenCV's resizeNN does."""
+    restatement is unpinned against cv2 itself; an 8x downscale picks rows 0, 8, 16 ... as OpenCV's resizeNN does.
+    The scale is formed as OpenCV forms it - ify = 1.0 / (dst / src) in double precision, not src / dst - so that
+    non-dyadic ratios round the same way."""
     H, W = a.shape[:2]
     h, w = size
-    ys = np.minimum(np.floor(np.arange(h) * (H / h)).astype(np.int64), H - 1)
-    xs = np.minimum(np.floor(np.arange(w) * (W / w)).astype(np.int64), W - 1)
+    ify, ifx = 1.0 / (float(h) / float(H)), 1.0 / (float(w) / float(W))
+    ys = np.minimum(np.floor(np.arange(h, dtype=np.float64) * ify).astype(np.int64), H - 1)
+    xs = np.minimum(np.floor(np.arange(w, dtype=np.float64) * ifx).astype(np.int64), W - 1)
     return a[ys][:, xs]
 
 

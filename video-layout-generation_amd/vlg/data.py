@@ -51,7 +51,12 @@ def device_prefetch(cpu_batches, device: torch.device, keys=BATCH_KEYS) -> Itera
     into a pinned host buffer and copied to HBM on a second HIP stream; the consumer's stream only waits for that copy's
     event.  Three rotating slots of pinned + device buffers: a slot is rewritten only after the copy that read its pinned
     half has finished (host-side event wait) and after the step that used its device half has been enqueued (stream-side
-    event wait).  Yields the SAME bytes in the SAME order as the plain path (tests/test_hip_variable_n.py)."""
+    event wait).  Yields the SAME bytes in the SAME order as the plain path (tests/test_hip_variable_n.py).
+
+    LIFETIME CONTRACT: a yielded batch aliases one of THREE rotating device slots - it is valid until the consumer asks
+    for the batch after the next one (i.e. for two iterations); anything that keeps batches longer (list(loader), a held
+    validation batch, a debugging hook) must clone them or build the loader with prefetch=False, which returns fresh
+    tensors (tests/test_hip_variable_n.py::test_prefetched_batches_alias_three_slots pins this)."""
     side = torch.cuda.Stream(device=device)
     slots = 3
     bufs: list = [dict() for _ in range(slots)]          # slot -> {shape signature: (pinned dict, device dict)}
@@ -115,7 +120,9 @@ class ClipLoader:
                  seed: int = 1024, shuffle: bool = True, device: Optional[torch.device] = None, keys=BATCH_KEYS,
                  prefetch: bool = True):
         """device = None: CPU batches.  device = a HIP device: device batches, staged through pinned memory one batch
-        ahead on a side stream (device_prefetch) unless prefetch=False (plain synchronous copies)."""
+        ahead on a side stream (device_prefetch) unless prefetch=False (plain synchronous copies).  Prefetched batches
+        alias three rotating device slots: a batch stays valid for two iterations (see device_prefetch); consumers that
+        retain batches pass prefetch=False."""
         self.clips, self.batch, self.rank, self.world = clips, batch, rank, world
         self.seed, self.shuffle, self.device, self.epoch = seed, shuffle, device, 0
         self.keys = tuple(keys)

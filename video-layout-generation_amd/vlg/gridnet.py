@@ -169,9 +169,10 @@ class GridNetHIP:
         self.img = self._block("lateral_out_img", "lateral", x0, img_out)
         self._alloc_params(params_from)
         lib = hip.load()
-        # workspace of the stride-1 convolutions' tail split (tiles beyond the last full round of 256 CUs, csrc/conv.hip)
+        # workspace of the forward convolutions (tail split: tiles beyond the last full round of 256 CUs; split-K of wide
+        # convolutions on small grids, csrc/conv.hip) - sized over EVERY convolution forward() hands it to
         self.ws_n = max([lib.vlg_conv3x3_fwd_workspace(c.out.geo.rows, c.x.cp, c.cout, c.out.cp)
-                         for c in self.tape if isinstance(c, _Conv) and c.stride == 1] + [0])
+                         for c in self.tape if isinstance(c, _Conv)] + [0])
         self.ws = torch.empty(self.ws_n, dtype=torch.float32, device=device) if self.ws_n else None
         self.forward_only = params_from is not None
         if self.forward_only:

@@ -128,5 +128,13 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+tracer = None     # optional callable(name, args) -> context manager | None: measurement hook (bench.py brackets launches with events)
+
+
 def call(name: str, *args) -> None:
-    check(getattr(load(), name)(*args), name)
+    cm = tracer(name, args) if tracer is not None else None
+    if cm is None:
+        check(getattr(load(), name)(*args), name)
+        return
+    with cm:
+        check(getattr(load(), name)(*args), name)

@@ -251,6 +251,25 @@ class FrameRollout:
         return torch.cat(img, dim=1), torch.cat(seg, dim=1)                          # trainer.py:470-471
 
 
+def random_state(shapes, seed: int) -> Dict[str, torch.Tensor]:
+    """torch's default initialisers for a state_dict of the given shapes - Conv2d weight and bias U(+-1/sqrt(fan_in)), PReLU
+    slope 0.25 - from one seeded generator: what a net without a checkpoint starts from (benchmarks; Trainer draws the
+    same distributions from the shared seed, reference src/main.py:57-60)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, shp in shapes.items():
+        shp = tuple(shp)
+        if shp == (1,) and not k.endswith("bias"):
+            out[k] = torch.full(shp, 0.25)
+            continue
+        wshape = shp if len(shp) == 4 else tuple(shapes.get(k[:-len("bias")] + "weight", (1, 64)))
+        fan_in = 1
+        for v in wshape[1:]:
+            fan_in *= v
+        out[k] = (torch.rand(shp, generator=g) * 2 - 1) / float(max(fan_in, 1)) ** 0.5
+    return out
+
+
 def synthetic_frames(n: int, H: int, W: int, seed: int = 1024) -> Dict[str, torch.Tensor]:
     """SURVEY.md section 8d Spec R inputs: frames U[0,1), seg ids U{0..19} (float maps for frames 1,2, int64 for
     frame 3 - reference src/folder.py:97-104), edge maps U[0,1) standing in for the frozen HED's output."""
