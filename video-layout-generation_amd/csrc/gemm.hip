@@ -88,7 +88,7 @@ __device__ __forceinline__ void vlg_epi_pace(int issued) {
 // barrier each) always runs beside the other group's main loop.  Both groups execute the same number of barriers: the
 // second group starts with nk / 2 empty slots, the first ends with them.
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool PP = false>
-__global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : (BK == 16 ? 3 : 2)) void gemm_f32_kernel(const GemmArgs g) {
     // Raised priority until the main loop starts.  It does NOT get this block's vector instructions past an older block's
     // MFMA stream (the vector ALU serves the oldest wave that has a matrix or vector instruction ready, whatever s_setprio
     // says: tools/micro/mfma_f32_valu_share.hip prio / two), but the prologue's loads and LDS writes are issued ahead of the
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, BK == 16 ? 3 
     const float* const gB = static_cast<const float*>(g.B);
     const float* const gAuxIn = static_cast<const float*>(g.aux_in);
     float* const gAuxOut = static_cast<float*>(g.aux_out);
-    constexpr int WM = (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 4 : 1);
+    // 128x128: 2 x 2 waves of 64x64; 64x64 (launches whose 128-wide tiles would leave CUs empty: small M): 2 x 2 waves of 32x32
+    constexpr int WM = (BM == BN && (BM == 128 || BM == 64)) ? 2 : (BM == 128 ? 4 : 1);
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int NCH = BK / 8;                    // 8-deep MFMA chunks per tile
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, BK == 16 ? 3 
     // matrix pipe.  Here the global loads are buffer loads - one loop-constant byte offset per thread and operand, the K
     // advance and the float4 number in the SCALAR offset - and two iterations are unrolled so the LDS buffer is a compile-
     // time constant and every LDS address is one loop-constant register plus an instruction immediate.
-    constexpr bool FAST = BM == 128 && BN == 128 && (EPI & (GEMM_A_GELU | GEMM_B_GELU)) == 0;
+    constexpr bool FAST = BM == BN && (BM == 128 || BM == 64) && (EPI & (GEMM_A_GELU | GEMM_B_GELU)) == 0;
     // A block may compute `run` consecutive N tiles of one row panel back to back (multi-round launches): the K loop
     // then simply CONTINUES into the next tile - the loads its last two iterations issue are the next tile's first two K
     // tiles, the LDS write of its last iteration is the next tile's tile 0 and the fragments read behind its last
@@ -683,8 +684,26 @@ static int gemm_run(const GemmArgs& g, int slots) {
     return best;
 }
 
+// 64x64 tiles (four 32x32 waves, four blocks per CU) for launches whose 128x128 tiles would leave CUs without a block: the
+// per-GPU share of a GLOBAL batch (reference src/trainer.py:148: 32 // 8 = 4 clips, M = 4 096 tokens) gives the N = 256
+// products 64 tiles for 256 CUs.  VLG_GEMM_SMALL=0 (read once) keeps 128x128 everywhere (A/B runs).
+static bool gemm_small_tiles() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLG_GEMM_SMALL");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return on == 1;
+}
+static bool gemm_wants_small(int64_t M, int N, int splits) {
+    return gemm_small_tiles() && ((M + 127) / 128) * (int64_t)((N + 127) / 128) * splits < 256;
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
 static int launch_gemm(GemmArgs g, hipStream_t s) {
+    if constexpr (BM == 128 && BN == 128 && !COLSUM && (EPI & (GEMM_A_GELU | GEMM_B_GELU)) == 0) {
+        if (gemm_wants_small(g.M, g.N, g.splits)) return launch_gemm<64, 64, A_KC, B_KC, EPI, COLSUM>(g, s);
+    }
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (g.N + BN - 1) / BN;
     g.run = 1;
@@ -817,13 +836,27 @@ extern "C" int vlg_linear_dgrad(const void* dY, int ldy, const void* W, int ldw,
 
 // split plan for the weight gradient: enough blocks to fill 256 CUs x 2 blocks, each split a
 // multiple of BK token rows
-static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per, bool bf16 = false) {
+// *small (native fp32 kernel only): 64x64 tiles, four resident blocks per CU, token ranges down to 128 rows - taken when the
+// 128x128 plan would leave CUs without a block (few tokens: the strong-scaling shard)
+static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per, bool bf16 = false, bool* small = nullptr) {
     const int bm = N <= 32 ? 32 : 128;
-    const int64_t tiles = ((N + bm - 1) / bm) * (int64_t)((K + 127) / 128);
+    int64_t tiles = ((N + bm - 1) / bm) * (int64_t)((K + 127) / 128);
     int64_t want = 512 / tiles;                      // blocks <= 512 = 256 CUs x 2 resident blocks: one full wave, no tail
-    const int64_t max_splits = (M + 255) / 256;
+    int64_t max_splits = (M + 255) / 256;
+    if (small) *small = false;
+    if (small && bm == 128 && gemm_small_tiles() && tiles * (want < max_splits ? (want < 1 ? 1 : want) : max_splits) < 256) {
+        *small = true;
+        tiles = ((N + 63) / 64) * (int64_t)((K + 63) / 64);
+        want = 1024 / tiles;
+        max_splits = (M + 127) / 128;
+    }
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;
+    if (small && *small) {
+        // equal token ranges where a slightly smaller count allows them (a ragged last range costs a whole block round)
+        for (int64_t c = want; c >= 1 && 4 * c >= 3 * want; --c)
+            if (M % (c * 64) == 0) { want = c; break; }
+    }
     int64_t p = (M + want - 1) / want;
     const int kt = 64;                               // whole K tiles, and an even number of the fp32 kernel's 32-row tiles (its
                                                      // loop runs them in pairs: an odd count costs one iteration on zeros)
@@ -832,14 +865,16 @@ static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per, bool 
     *splits = (int)((M + p - 1) / p);
 }
 
+// (the small-tile plan exists for the native fp32 kernel only: flags without the bf16 / split bits)
+static bool wgrad_native(int flags) { return (flags & (VLG_EPI_BF16 | VLG_EPI_SPLIT3 | VLG_EPI_ACT_GELU)) == 0; }
 extern "C" int vlg_linear_wgrad_slabs(int64_t M, int N, int K) {
-    int splits; int64_t per;
-    wgrad_plan(M, N, K, &splits, &per);
+    int splits; int64_t per; bool small;
+    wgrad_plan(M, N, K, &splits, &per, false, &small);
     return splits;
 }
 extern "C" int vlg_linear_wgrad_slabs_for(int64_t M, int N, int K, int flags) {
-    int splits; int64_t per;
-    wgrad_plan(M, N, K, &splits, &per, (flags & VLG_EPI_BF16) != 0);
+    int splits; int64_t per; bool small;
+    wgrad_plan(M, N, K, &splits, &per, (flags & VLG_EPI_BF16) != 0, wgrad_native(flags) ? &small : nullptr);
     return splits;
 }
 
@@ -852,7 +887,8 @@ extern "C" int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
     GemmArgs g{};
     g.A = dY; g.B = X; g.C = slabs;
     g.M = N; g.N = K; g.Kc = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
-    wgrad_plan(M, N, K, &g.splits, &g.kc_per_split, (flags & VLG_EPI_BF16) != 0);
+    bool small = false;
+    wgrad_plan(M, N, K, &g.splits, &g.kc_per_split, (flags & VLG_EPI_BF16) != 0, wgrad_native(flags) ? &small : nullptr);
     if (slab_capacity < (int64_t)g.splits * slab_stride) return VLG_ERR_SHAPE;      // the caller's buffer must hold every slab
     g.slab_stride = slab_stride; g.colsum_off = (int64_t)N * K;
     hipStream_t s = (hipStream_t)stream;
@@ -864,6 +900,7 @@ extern "C" int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
     if (flags & VLG_EPI_SPLIT3) return (io == 0 && !(flags & VLG_EPI_ACT_GELU)) ? vlg_gemm_split_wgrad(g, s) : VLG_ERR_SHAPE;
     if (flags & VLG_EPI_ACT_GELU)                     // X = gelu(stored pre-activation): weight gradient of the FFN's second projection
         return N <= 32 ? VLG_ERR_SHAPE : launch_gemm<128, 128, false, false, GEMM_B_GELU, true>(g, s);
+    if (small) return launch_gemm<64, 64, false, false, VLG_EPI_NONE, true>(g, s);
     return N <= 32 ? launch_gemm<32, 128, false, false, VLG_EPI_NONE, true>(g, s)
                    : launch_gemm<128, 128, false, false, VLG_EPI_NONE, true>(g, s);
 }
