@@ -229,6 +229,8 @@ def reference_step_leg(dev, cpu: bool = True):
     from vlg.image_engine import ImageEngine, random_state, synthetic_frames
     H = W = 256
     out = {"gflop_per_sample": round(REFERENCE_GFLOP_PER_SAMPLE, 1), "frames": "%dx%d" % (H, W),
+           "gflop_note": "GridNet fwd+bwd 188.7 + HED 2 x 40.1 (the third HED call of trainer.py:214-216 only feeds tensorboard: not made) + "
+                         "VGG19[:27] 2 x 46.1 fwd + 46.1 input gradient (SURVEY.md section 6)",
            "step": "src/trainer.py:193-258 with the Appendix-A repairs: prep -> CoordGridNet -> 40 L1 + 20 (VGG + GD + SSIM) + 10 CE "
                    "-> backward -> Adam; HED fused map x2 under no-grad"}
     for b in (4, 32):
@@ -252,23 +254,31 @@ def reference_step_leg(dev, cpu: bool = True):
             torch.cuda.synchronize()
         finally:
             hip.tracer = None
+        # per shape group: (summed ms over the two bracketed steps, launches per step, algorithmic GFLOP per launch).  `rows`
+        # counts the halo-padded pixels of a level; the algorithmic work is over the b * h * w real ones (rows = b (h + 2)(w + 2),
+        # square levels) - exact for the stride-1 convolutions, which every shape that matters here is
         groups = []
         for (name, rows, cin, cout), ev in ct.rec.items():
-            ms = [s.elapsed_time(e) for s, e in ev]
-            groups.append((sum(ms), name, rows, cin, cout, len(ms) // 2, sum(ms) / len(ms)))
-        total_conv = sum(g[0] for g in groups) / 2
-        groups.sort(reverse=True)
-        # the dominant convolution shape.  `rows` counts the halo-padded pixels of the level; the algorithmic work is over the
-        # b * h * w real ones (level h x w from rows = b (h + 2)(w + 2), square levels) and the real channel counts - equal to
-        # the padded ones from 32 channels up, which every shape that can lead this list has.
-        tot, name, rows, cin, cout, launches, avg_ms = groups[0]
-        side = int(round((rows / b) ** 0.5)) - 2
-        gflop = 2.0 * b * side * side * 9 * cin * cout / 1e9
-        rec["conv_ms_per_step"] = round(total_conv, 3)
-        rec["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_kernel via %s, %d->%d channels at %dx%dx%d" % (name, cin, cout, b, side, side),
-                           "launches_per_step": launches, "avg_launch_us": round(1e3 * avg_ms, 2), "gflop_per_launch": round(gflop, 3),
-                           "achieved": round(gflop / avg_ms, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(gflop / avg_ms / PEAK_F32_MFMA_TFLOPS, 4), "share_of_step": round(tot / 2 / (1e3 * dt), 4)}
+            ms = sum(s.elapsed_time(e) for s, e in ev)
+            side = int(round((rows / b) ** 0.5)) - 2
+            groups.append({"entry": name, "cin": cin, "cout": cout, "side": side, "ms": ms, "launches": len(ev) // 2,
+                           "gflop": 2.0 * b * side * side * 9 * cin * cout / 1e9})
+        rec["conv_ms_per_step"] = round(sum(g["ms"] for g in groups) / 2, 3)
+        # the dominant kernel of the step's rocprof summary (profiles/r0*_reference_step_kernel_stats.csv) is
+        # conv_gemm_kernel<0, 128, 128, 32>: forward launches on 128 x 128 tiles = the frozen trunks' layers with >= 128 output
+        # channels and >= 64 input channels (channel counts there are multiples of 32: padded = real)
+        fam = [g for g in groups if g["entry"] == "vlg_conv3x3_fwd" and g["cout"] >= 128 and g["cin"] >= 64]
+        if fam:
+            ms, n = sum(g["ms"] for g in fam), sum(2 * g["launches"] for g in fam)
+            gf = sum(g["gflop"] * 2 * g["launches"] for g in fam)
+            rec["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_kernel<0, 128, 128, 32> (forward, >= 128 output channels: VGG19 / HED trunks)",
+                               "launches_per_step": n // 2, "avg_launch_us": round(1e3 * ms / n, 2), "gflop_per_launch": round(gf / n, 3),
+                               "achieved": round(gf / ms, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(gf / ms / PEAK_F32_MFMA_TFLOPS, 4), "share_of_step": round(ms / 2 / (1e3 * dt), 4)}
+        top = sorted(groups, key=lambda g: -g["ms"])[:4]
+        rec["top_conv_shapes"] = [{"entry": g["entry"], "shape": "%d->%d @ %dx%dx%d" % (g["cin"], g["cout"], b, g["side"], g["side"]),
+                                   "launches_per_step": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / (2 * g["launches"]), 2),
+                                   "tflops": round(g["gflop"] * 2 * g["launches"] / g["ms"], 1)} for g in top]
         out["b%d" % b] = rec
         del eng, batch
         torch.cuda.empty_cache()
@@ -567,6 +577,12 @@ def main():
                                               "kernel_tflops": round(w["flops_per_launch"] / (w["avg_ms"] * 1e-3) / 1e12, 1)}
                     line[key]["families"] = {k: {"avg_us": round(1e3 * v["avg_ms"], 2), "gbs": round(v["bytes_per_launch"] / (v["avg_ms"] * 1e-3) / 1e9, 1)}
                                              for k, v in fam.items()}
+                    # the mode is HBM-bound: the WHOLE step against the HBM roofline = sum of every launch's algorithmic bytes
+                    # (operands once + outputs once, per launch; the slab reductions' reads are not counted) / step time
+                    step_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in fam.values()) / 2.0
+                    line[key]["roofline_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": int(step_bytes),
+                                                  "achieved": round(step_bytes / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                  "frac": round(step_bytes / dt / 1e9 / PEAK_HBM_GBS, 4)}
                 del e2
             # informational: the same native fp32 step with the weight gradients on a second HIP stream (LayoutEngine option
             # VLG_OVERLAP_WGRAD=1): launch boundaries and the bandwidth-bound kernels of the chain then overlap with them.  NOT

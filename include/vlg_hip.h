@@ -60,7 +60,8 @@ int vlg_embed_fwd(const int64_t* slot_class, const float* slot_box,
                   const float* cls_emb, const float* box_w, const float* box_b,
                   const float* time_emb, float* x,
                   int B, int T, int N, int d, int vocab, void* stream);
-int vlg_embed_bwd_slabs(void);             /* number of slabs vlg_embed_bwd writes */
+int vlg_embed_bwd_slabs(void);             /* upper bound of the number of slabs any vlg_embed_bwd launch writes */
+int vlg_embed_bwd_slabs_for(int B, int T, int N, int d, int vocab);   /* slabs THIS shape's launch writes (<= the bound): reduce exactly these */
 int vlg_embed_bwd(const float* dx, const int64_t* slot_class, const float* slot_box,
                   float* slabs, int64_t slab_stride, int64_t slab_capacity,
                   int B, int T, int N, int d, int vocab, void* stream);
@@ -153,7 +154,8 @@ int vlg_attention_bwd_bf16(const vlg_bf16* qkv, const vlg_bf16* dout, vlg_bf16* 
  *   smooth-L1, IoU : SELF-ORACLE
  * out/dout are [rows, ld] with columns [0,C) = logits, [C,C+4) = raw box.
  * loss_out[4] = {total, smooth_l1, iou, ce}.  scratch holds >= vlg_layout_loss_scratch()
- * floats. */
+ * floats, 16-byte aligned, ZERO-INITIALISED ONCE by the caller: scratch[1] is the integer ticket by which the last
+ * block of the (single) launch folds the per-block partials into loss_out; that block leaves it zero again. */
 int vlg_layout_loss_scratch(void);
 int vlg_layout_loss(const float* out, int ld, const int64_t* tgt_class, const float* tgt_box,
                     const float* valid, float* dout, float* loss_out, float* scratch,

@@ -59,7 +59,8 @@ def test_embed_fwd_bwd(H, dev, B, T, N, d):
     # backward
     dx = gy.permute(0, 2, 1, 3).contiguous().view(B * N * T, d).to(dev)
     L = vocab * d + d * 4 + d + T * d
-    ns = H.load().vlg_embed_bwd_slabs()
+    ns = H.load().vlg_embed_bwd_slabs_for(B, T, N, d, vocab)
+    assert 1 <= ns <= H.load().vlg_embed_bwd_slabs()
     slabs = torch.empty(ns * L, device=dev)
     H.call("vlg_embed_bwd", dx.data_ptr(), clsd.data_ptr(), boxd.data_ptr(), slabs.data_ptr(), L, slabs.numel(), B, T, N, d, vocab,
            stream())
@@ -91,7 +92,7 @@ def test_embed_class_table_matches_reference_embedding(H, dev):
     assert torch.equal(got, torch.from_numpy(z["out"]).reshape(B, T, N, d))  # a row gather: exact
     dx = torch.from_numpy(z["r"]).reshape(B, T, N, d).permute(0, 2, 1, 3).contiguous().view(B * N * T, d).to(dev)
     L = vocab * d + d * 4 + d + T * d
-    ns = H.load().vlg_embed_bwd_slabs()
+    ns = H.load().vlg_embed_bwd_slabs_for(B, T, N, d, vocab)
     slabs = torch.empty(ns * L, device=dev)
     H.call("vlg_embed_bwd", dx.data_ptr(), ids.data_ptr(), box.data_ptr(), slabs.data_ptr(), L, slabs.numel(), B, T, N, d, vocab,
            stream())

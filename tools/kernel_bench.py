@@ -83,11 +83,16 @@ def main():
     boxes = torch.rand(B, T, N, 4, device=dev)
     tabs = r(vocab * d + d * 4 + d + T * d)
     L_emb = vocab * d + d * 4 + d + T * d
-    eslabs = torch.empty(lib.vlg_embed_bwd_slabs() * L_emb, device=dev)
+    eslabs = torch.empty(lib.vlg_embed_bwd_slabs_for(B, T, N, d, vocab) * L_emb, device=dev)
     add("embed fwd", 4.0 * M * d + 24.0 * M, "B", lambda: hip.call("vlg_embed_fwd", P(ids), P(boxes), P(tabs), tabs.data_ptr() + 4 * vocab * d, tabs.data_ptr() + 4 * (vocab * d + 4 * d),
                                                                      tabs.data_ptr() + 4 * (vocab * d + 5 * d), P(y_d), B, T, N, d, vocab, S))
     add("embed bwd", 4.0 * M * d + 24.0 * M, "B", lambda: hip.call("vlg_embed_bwd", P(x_d), P(ids), P(boxes), P(eslabs), L_emb, eslabs.numel(), B, T, N, d, vocab, S))
-    add("embed bwd reduce", 4.0 * L_emb * (lib.vlg_embed_bwd_slabs() + 1), "B", lambda: hip.call("vlg_reduce_slabs", P(eslabs), L_emb, lib.vlg_embed_bwd_slabs(), P(red_dst), L_emb, S))
+    add("embed bwd reduce", 4.0 * L_emb * (lib.vlg_embed_bwd_slabs_for(B, T, N, d, vocab) + 1), "B", lambda: hip.call("vlg_reduce_slabs", P(eslabs), L_emb, lib.vlg_embed_bwd_slabs_for(B, T, N, d, vocab), P(red_dst), L_emb, S))
+    hout, hdout = r(M, 24), torch.empty(M, 24, device=dev)
+    tcls, tbox, tvalid = torch.randint(0, 20, (B, T, N), device=dev), torch.rand(B, T, N, 4, device=dev) * 0.5 + 0.25, torch.ones(B, T, N, device=dev)
+    lscr, lout = torch.zeros(lib.vlg_layout_loss_scratch(), device=dev), torch.zeros(4, device=dev)
+    add("layout loss (value + gradient)", (2.0 * 96 + 28) * M, "B", lambda: hip.call("vlg_layout_loss", P(hout), 24, P(tcls), P(tbox), P(tvalid), P(hdout), P(lout), P(lscr),
+                                                                                B, T, N, 20, 0.1, 1e-7, 40.0, 20.0, 10.0, S))
     add("layernorm fwd", 8.0 * M * d, "B", lambda: hip.call("vlg_layernorm_fwd", P(x_d), P(g), P(g), P(y_d), P(stats[0]), P(stats[1]), M, d, 1e-5, S))
     add("layernorm bwd", 16.0 * M * d, "B", lambda: hip.call("vlg_layernorm_bwd", P(x_d), P(y_d), P(stats[0]), P(stats[1]), P(g), P(x_d), P(y_d), P(slabs), 2 * d, slabs.numel(), M, d, S))
 

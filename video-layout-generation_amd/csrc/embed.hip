@@ -9,19 +9,22 @@
 //        [cls_emb | box_w | box_b | time_emb] which vlg_reduce_slabs sums (bitwise
 //        reproducible - no float atomics).  Algorithmic bytes: 4*M*d read.
 #include "common.h"
+#include <stdlib.h>
 
 #define EMBED_BWD_SLABS 256
 
-// Thread (slot, q) of a block owns channels 4q .. 4q+3 of every row the block's slot walks (d/4 threads per row,
-// 1024/d rows in flight per block): the box projection rows and the bias of those channels are loaded ONCE, the
-// row's class id and box are one broadcast load each, and per row the thread does two coalesced 16-B table reads
-// (class row, frame row) and one coalesced 16-B store.  Round 1 re-read 4 box_w float4 + ids + box per float4
-// written (22 % of the HBM roofline).
+// A block owns SPB whole (clip, slot) sequences (one at the metric shape: T rows of d floats = a contiguous 16 KB tile of x).
+// Thread (slot, q) owns channels 4q .. 4q+3 of the rows slot, slot + rpb, ... of that tile (d/4 threads per row, 1024/d rows
+// per pass): the box projection rows and the bias of those channels are loaded ONCE, the row's class id and box are one
+// broadcast load each, and per row the thread does two coalesced 16-B table reads (class row, frame row) and one coalesced
+// 16-B store.  Row -> (clip, frame, slot) costs one 32-bit division per ROW PASS now: round 2 walked a flat token index
+// with three 64-bit divisions per row (hundreds of vector instructions each) - the kernel was ALU-bound at 21 % of the
+// HBM roofline, not latency-bound as believed; round 1 re-read 4 box_w float4 + ids + box per float4 written.
 __global__ __launch_bounds__(256) void embed_fwd_kernel(
     const int64_t* __restrict__ slot_class, const float* __restrict__ slot_box,
     const float* __restrict__ cls_emb, const float* __restrict__ box_w,
     const float* __restrict__ box_b, const float* __restrict__ time_emb,
-    float* __restrict__ x, int B, int T, int N, int d, int vocab) {
+    float* __restrict__ x, int n_seq, int T, int N, int d, int vocab, int spb) {
     const int lpr = d >> 2;                                   // threads per row
     const int q = threadIdx.x % lpr, slot = threadIdx.x / lpr, rpb = blockDim.x / lpr;
     if (slot >= rpb) return;
@@ -29,14 +32,14 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     const float4 w0 = ld4(box_w + (int64_t)(c + 0) * 4), w1 = ld4(box_w + (int64_t)(c + 1) * 4);
     const float4 w2 = ld4(box_w + (int64_t)(c + 2) * 4), w3 = ld4(box_w + (int64_t)(c + 3) * 4);
     const float4 bb = ld4(box_b + c);
-    const int64_t M = (int64_t)B * T * N;
+    const unsigned rows = (unsigned)spb * (unsigned)T, uT = (unsigned)T, uN = (unsigned)N;
 #pragma unroll 4
-    for (int64_t m = (int64_t)blockIdx.x * rpb + slot; m < M; m += (int64_t)gridDim.x * rpb) {
-        const int t = (int)(m % T);
-        const int64_t bn = m / T;
-        const int n = (int)(bn % N);
-        const int64_t b = bn / N;
-        const int64_t src = (b * T + t) * N + n;
+    for (unsigned r = (unsigned)slot; r < rows; r += (unsigned)rpb) {
+        const unsigned sl = r / uT, t = r - sl * uT;
+        const unsigned seq = blockIdx.x * (unsigned)spb + sl;
+        if (seq >= (unsigned)n_seq) break;
+        const unsigned b = seq / uN, n = seq - b * uN;
+        const int64_t src = ((int64_t)b * T + t) * N + n;
         int64_t cls = slot_class[src];
         cls = cls < 0 ? 0 : (cls >= vocab ? vocab - 1 : cls);   // host validates; never fault
         const float4 bx = ld4(slot_box + src * 4);
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
         acc.y += bx.x * w1.x + bx.y * w1.y + bx.z * w1.z + bx.w * w1.w;
         acc.z += bx.x * w2.x + bx.y * w2.y + bx.z * w2.z + bx.w * w2.w;
         acc.w += bx.x * w3.x + bx.y * w3.y + bx.z * w3.z + bx.w * w3.w;
-        st4(x + m * d + c, acc);
+        st4(x + ((int64_t)seq * T + t) * d + c, acc);
     }
 }
 
@@ -60,7 +63,7 @@ __device__ __forceinline__ float4 f4_fma(float s, float4 v, float4 a) {
 }
 __device__ __forceinline__ float4 f4_scale(float4 v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
 
-template <int TT>
+template <int TT, bool PF>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ slot_class,
                                                        const float* __restrict__ slot_box, float* __restrict__ slabs,
                                                        int64_t slab_stride, int B, int N, int d, int vocab, int rows, int G) {
@@ -88,20 +91,32 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     // 384 / 448 a wave mixes two groups (and their trip counts), so those widths - and d = 64 with T = 32 - load directly
     const bool shuffled = lpr >= TT && (lpr < 64 ? (64 % lpr) == 0 : (lpr & 63) == 0);
     if (live) {
-        for (int64_t seq = (int64_t)blockIdx.x * G + grp; seq < n_seq; seq += (int64_t)gridDim.x * G) {
+        // the rows, ids and boxes of the NEXT sequence are requested before the current one is accumulated (two sequences
+        // per group at the metric shape: the second one's HBM latency hides behind the first one's LDS read-modify-writes)
+        const int64_t stride = (int64_t)gridDim.x * G;
+        int64_t seq = (int64_t)blockIdx.x * G + grp;
+        float4 gv[TT], gn[TT];
+        int my_cls = 0, nx_cls = 0;
+        float4 my_box = f4_zero(), nx_box = f4_zero();
+        auto fetch = [&](int64_t sq, float4 (&rows_)[TT], int& cls_, float4& box_) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) rows_[t] = ld4(dx + (sq * TT + t) * d + c);       // TT independent 16-B loads in flight
+            if (shuffled && tl < TT) {
+                const int64_t b = sq / N;
+                const int64_t src = (b * TT + tl) * N + (sq - b * N);
+                const int64_t cl = slot_class[src];
+                cls_ = (int)(cl < 0 ? 0 : (cl >= vocab ? vocab - 1 : cl));
+                box_ = ld4(slot_box + src * 4);
+            }
+        };
+        constexpr bool PREFETCH = PF && TT <= 16;          // (TT = 32: two row sets would not fit the register file)
+        if (PREFETCH && seq < n_seq) fetch(seq, gv, my_cls, my_box);
+        for (; seq < n_seq; seq += stride) {
             const int64_t b = seq / N;
             const int n = (int)(seq - b * N);
-            float4 gv[TT];
-#pragma unroll
-            for (int t = 0; t < TT; ++t) gv[t] = ld4(dx + (seq * TT + t) * d + c);     // TT independent 16-B loads in flight
-            int my_cls = 0;
-            float4 my_box = f4_zero();
-            if (shuffled && tl < TT) {
-                const int64_t src = (b * TT + tl) * N + n;
-                const int64_t cl = slot_class[src];
-                my_cls = (int)(cl < 0 ? 0 : (cl >= vocab ? vocab - 1 : cl));
-                my_box = ld4(slot_box + src * 4);
-            }
+            if constexpr (!PREFETCH) fetch(seq, gv, my_cls, my_box);
+            const bool more = PREFETCH && seq + stride < n_seq;
+            if (more) fetch(seq + stride, gn, nx_cls, nx_box);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
                 const float4 g = gv[t];
@@ -122,6 +137,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
                 b_acc = f4_add(b_acc, g);
                 w_acc0 = f4_fma(bx.x, g, w_acc0); w_acc1 = f4_fma(bx.y, g, w_acc1);
                 w_acc2 = f4_fma(bx.z, g, w_acc2); w_acc3 = f4_fma(bx.w, g, w_acc3);
+            }
+            if (more) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t) gv[t] = gn[t];
+                my_cls = nx_cls;
+                my_box = nx_box;
             }
         }
     }
@@ -175,41 +196,66 @@ extern "C" int vlg_embed_fwd(const int64_t* slot_class, const float* slot_box, c
         !vlg_aligned16(box_b) || !vlg_aligned16(time_emb) || !vlg_aligned16(x)) return VLG_ERR_ALIGN;
     if (d > 1024) return VLG_ERR_SHAPE;                       // d/4 threads of a 256-thread block own one row
     const int rpb = 1024 / d;                                 // rows in flight per block (d <= 1024)
-    const int64_t rows = (int64_t)B * T * N;
-    int64_t blocks = (rows + rpb - 1) / rpb;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    const int64_t n_seq = (int64_t)B * N;
+    if (n_seq * T >= (1ll << 31)) return VLG_ERR_SHAPE;       // 32-bit row arithmetic in the kernel
+    const int spb = rpb > T ? rpb / T : 1;                    // whole sequences per block (short clips: several)
+    const int64_t blocks = (n_seq + spb - 1) / spb;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       slot_class, slot_box, cls_emb, box_w, box_b, time_emb, x, B, T, N, d, vocab);
+                       slot_class, slot_box, cls_emb, box_w, box_b, time_emb, x, (int)n_seq, T, N, d, vocab, spb);
     return vlg_last_error();
 }
 
-extern "C" int vlg_embed_bwd_slabs(void) { return EMBED_BWD_SLABS; }
+extern "C" int vlg_embed_bwd_slabs(void) { return EMBED_BWD_SLABS; }          // the most any launch writes
+
+static int embed_bwd_groups(int T, int d, int vocab) {
+    const int rows = vocab > T + 5 ? vocab : T + 5;
+    int G = 1024 / d;                                     // groups per block: d/4 threads each
+    while (G > 1 && (size_t)G * rows * d * sizeof(float) > 96 * 1024) G >>= 1;
+    return G;
+}
+// slabs (= blocks) of a launch: one group per sequence until the chip is full (few clips: fewer blocks, fewer slabs to write
+// and to reduce - the 4-clip shard has 256 sequences = 64 blocks, and wrote 256 slabs = 11 MB before)
+extern "C" int vlg_embed_bwd_slabs_for(int B, int T, int N, int d, int vocab) {
+    if (B < 1 || N < 1 || d < 64 || d > 1024 || vocab < 1) return EMBED_BWD_SLABS;
+    const int G = embed_bwd_groups(T, d, vocab);
+    const int64_t want = ((int64_t)B * N + G - 1) / G;
+    return (int)(want < EMBED_BWD_SLABS ? want : EMBED_BWD_SLABS);
+}
 
 extern "C" int vlg_embed_bwd(const float* dx, const int64_t* slot_class, const float* slot_box,
                              float* slabs, int64_t slab_stride, int64_t slab_capacity, int B, int T, int N, int d,
                              int vocab, void* stream) {
     if (B < 1 || N < 1 || d < 64 || d > 1024 || (d & 63) || vocab < 1) return VLG_ERR_SHAPE;
-    if (slab_capacity < (int64_t)EMBED_BWD_SLABS * slab_stride) return VLG_ERR_SHAPE;      // the caller's buffer must hold every slab
+    const int n_blocks = vlg_embed_bwd_slabs_for(B, T, N, d, vocab);
+    if (slab_capacity < (int64_t)n_blocks * slab_stride) return VLG_ERR_SHAPE;             // the caller's buffer must hold every slab
     const int64_t need = (int64_t)vocab * d + (int64_t)d * 4 + d + (int64_t)T * d;
     if (slab_stride < need || (slab_stride & 3)) return VLG_ERR_SHAPE;
     if (!vlg_aligned16(slot_box) || !vlg_aligned16(slabs)) return VLG_ERR_ALIGN;
     const int rows = vocab > T + 5 ? vocab : T + 5;
-    int G = 1024 / d;                                     // groups per block: d/4 threads each
-    while (G > 1 && (size_t)G * rows * d * sizeof(float) > 96 * 1024) G >>= 1;
+    const int G = embed_bwd_groups(T, d, vocab);
     const size_t lds = (size_t)G * rows * d * sizeof(float);
     if (lds > 160 * 1024 || (slab_stride & 3) || (((int64_t)vocab * d) & 3)) return VLG_ERR_SHAPE;
-    const dim3 grid(EMBED_BWD_SLABS), block(256);
+    const dim3 grid((unsigned)n_blocks), block(256);
+    // VLG_EMBED_PREFETCH=1 (read once): request the next sequence's rows before accumulating the current one.  Measured
+    // (tools/kernel_bench.py, one box): 20.3 us against 19.3 us without at the metric shape - the second row set takes the
+    // kernel to 256 registers and the accumulation is not what the loads wait for.  OFF.
+    static int prefetch = -1;
+    if (prefetch < 0) { const char* e = getenv("VLG_EMBED_PREFETCH"); prefetch = e ? atoi(e) : 0; }
     hipStream_t s = (hipStream_t)stream;
 #define EMBED_BWD_LAUNCH(TT)                                                                                    \
     {                                                                                                           \
         static size_t granted = 0;        /* the attribute call costs tens of microseconds of host time: once per size */ \
         if (lds > granted) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+            (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<TT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds);                                                                      \
+            (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<TT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 (int)lds);                                                                      \
             granted = lds;                                                                                      \
         }                                                                                                       \
-        hipLaunchKernelGGL(embed_bwd_kernel<TT>, grid, block, lds, s, dx, slot_class, slot_box, slabs,          \
-                           slab_stride, B, N, d, vocab, rows, G);                                               \
+        if (prefetch) hipLaunchKernelGGL((embed_bwd_kernel<TT, true>), grid, block, lds, s, dx, slot_class, slot_box, slabs, \
+                                         slab_stride, B, N, d, vocab, rows, G);                                 \
+        else hipLaunchKernelGGL((embed_bwd_kernel<TT, false>), grid, block, lds, s, dx, slot_class, slot_box, slabs,        \
+                                slab_stride, B, N, d, vocab, rows, G);                                          \
     }
     switch (T) {
         case 4:  EMBED_BWD_LAUNCH(4) break;

@@ -695,8 +695,27 @@ static bool gemm_small_tiles() {
     }
     return on == 1;
 }
+// Measured (tools/shard_bench.py, one box): 64x64 tiles pay up to ~1 024 blocks of 128x128 - four resident blocks per CU
+// overlap one block's prologue / epilogue with the others' MFMAs - B = 4: 1.75 -> 1.12 ms, B = 8: 1.87 -> 1.76, B = 16: 3.12 -> 3.01,
+// B = 32 (the d x d products): 5.59 -> 5.55.
+static int gemm_small_below() {                  // VLG_GEMM_SMALL_BELOW (read once): 128x128 block count under which 64x64 tiles are taken
+    static int thr = -1;
+    if (thr < 0) {
+        const char* e = getenv("VLG_GEMM_SMALL_BELOW");
+        thr = e ? atoi(e) : 1025;
+    }
+    return thr;
+}
+static int gemm_small_below_wgrad() {            // the same for the weight-gradient plan (VLG_GEMM_SMALL_BELOW_WGRAD)
+    static int thr = -1;
+    if (thr < 0) {
+        const char* e = getenv("VLG_GEMM_SMALL_BELOW_WGRAD");
+        thr = e ? atoi(e) : 385;                     // under 3/4 of the 512 slots of the 128x128 plan (B = 32 keeps that plan: 504-512 blocks)
+    }
+    return thr;
+}
 static bool gemm_wants_small(int64_t M, int N, int splits) {
-    return gemm_small_tiles() && ((M + 127) / 128) * (int64_t)((N + 127) / 128) * splits < 256;
+    return gemm_small_tiles() && ((M + 127) / 128) * (int64_t)((N + 127) / 128) * splits < gemm_small_below();
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM>
@@ -844,10 +863,12 @@ static void wgrad_plan(int64_t M, int N, int K, int* splits, int64_t* per, bool 
     int64_t want = 512 / tiles;                      // blocks <= 512 = 256 CUs x 2 resident blocks: one full wave, no tail
     int64_t max_splits = (M + 255) / 256;
     if (small) *small = false;
-    if (small && bm == 128 && gemm_small_tiles() && tiles * (want < max_splits ? (want < 1 ? 1 : want) : max_splits) < 256) {
+    if (small && bm == 128 && gemm_small_tiles() && tiles * (want < max_splits ? (want < 1 ? 1 : want) : max_splits) < gemm_small_below_wgrad()) {
         *small = true;
         tiles = ((N + 63) / 64) * (int64_t)((K + 63) / 64);
-        want = 1024 / tiles;
+        static int slots = -1;                       // VLG_WGRAD_SMALL_SLOTS (read once; A/B runs)
+        if (slots < 0) { const char* e = getenv("VLG_WGRAD_SMALL_SLOTS"); slots = e ? atoi(e) : 1024; }
+        want = slots / tiles;
         max_splits = (M + 127) / 128;
     }
     if (want > max_splits) want = max_splits;

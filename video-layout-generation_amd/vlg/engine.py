@@ -481,10 +481,11 @@ class LayoutEngine:
         lib = hip.load()
         s = self._stream()
         emb_len = self.layout["l0.ln1_g"][0]
-        arena = self._arena("s", lib.vlg_embed_bwd_slabs() * emb_len)
+        n_slabs = lib.vlg_embed_bwd_slabs_for(B, T, N, d, cfg.vocab)          # by shape: few clips write (and reduce) few slabs
+        arena = self._arena("s", n_slabs * emb_len)
         self._timed("embed_bwd", 0.0, "vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(arena),
                     emb_len, arena.numel(), B, T, N, d, cfg.vocab, s, nbytes=4.0 * M * d + 24.0 * M)
-        self._reduce("s", emb_len, lib.vlg_embed_bwd_slabs(), 0, emb_len)
+        self._reduce("s", emb_len, n_slabs, 0, emb_len)
         self._join_reduces()                       # the gradient buffer is complete for whoever runs next on this stream
         if reducer is not None:
             reducer.ready("embed")

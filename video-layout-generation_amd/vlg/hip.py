@@ -30,6 +30,7 @@ SIGNATURES = {
     "vlg_debug_set_gemm_run": (None, [I]),
     "vlg_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "vlg_embed_bwd_slabs": (I, []),
+    "vlg_embed_bwd_slabs_for": (I, [I, I, I, I, I]),
     "vlg_embed_bwd": (I, [P, P, P, P, L, L, I, I, I, I, I, P]),
     "vlg_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
     "vlg_layernorm_fwd_bf16": (I, [P, P, P, P, P, P, L, I, F, P]),

@@ -133,6 +133,25 @@ class VggLossHIP:
                      self._pp("_zero") if relu else 0, 0, g.rows, tin.cp, co, tout.cp, g.wp, tin.cp,
                      CEPI_CIN4 if (ci <= 4 and not relu) else 0, ptr(self.ws), self.ws_n, s)
 
+    def preactivations(self) -> Dict[str, torch.Tensor]:
+        """Every convolution's output BEFORE its ReLU, as (b, C, h, w) tensors keyed by the torchvision module name
+        ("features.<i>"), for the image the trunk ran LAST (loss_and_grad: `output`), plus "target" = the kept
+        pre-activation features of the target.  These fix every kink decision the backward took - ReLU' = [pre > 0], the
+        2x2 max-pool's argmax (taken on the pre-activation: ReLU commutes with max) and the sign of the final L1 - so a
+        test can evaluate a smooth fp64 restatement ON that pattern (tests/test_hip_vgg.py::test_vgg_gradient_strict_given_pattern)."""
+        s = torch.cuda.current_stream().cuda_stream
+        out = {}
+
+        def nchw(t: _PT) -> torch.Tensor:
+            o = torch.empty(self.b, t.C, t.geo.H, t.geo.W, dtype=torch.float32, device=self.device)
+            call("vlg_padded_to_nchw", t.ptr, ptr(o), self.b, t.C, t.geo.H, t.geo.W, t.cp, s)
+            return o
+        for op in self.ops:
+            if op[0] == "conv":
+                out[op[1]] = nchw(op[3])
+        out["target"] = nchw(self.feat_tgt)
+        return out
+
     def loss_and_grad(self, output: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0, want_grad: bool = True):
         """Returns (loss[1] device tensor, d(grad_scale * loss)/d output as (b,3,H,W) or None)."""
         b, H, W = self.b, self.H, self.W
