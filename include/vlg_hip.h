@@ -40,15 +40,21 @@ extern "C" {
 int         vlg_abi_version(void);
 const char* vlg_build_arch(void);          /* "gfx950" */
 
-/* diagnostic only (tools/diag/gemm_shader_clock.py): when set to a device buffer of 2*blocks uint64, every block of the next
- * GEMM launches records {shader-clock ticks, 100 MHz ticks} of its main loop; NULL switches it off */
+/* DIAGNOSTIC BUILD ONLY (`make -C csrc diag` -> libvlg_hip_diag.so, compiled with -DVLG_DIAG; the product library does
+ * NOT export these and keeps no mutable process-wide state - its only configuration is environment variables read once).
+ * Development tools load that build through VLG_HIP_LIB (tools/diag, tools/ab). */
+#ifdef VLG_DIAG
+/* when set to a device buffer of 2*blocks uint64, every block of the next GEMM launches records {shader-clock ticks,
+ * 100 MHz ticks} of its main loop; NULL switches it off (tools/diag/gemm_shader_clock.py) */
 void vlg_debug_set_clock_probe(unsigned long long* buf);
-/* diagnostic only (tools/ab/gemm_ab.py): force the contraction depth per LDS tile of the 128x128 fp32 GEMM kernels
- * (16 | 32; 0 = the library's own choice per epilogue; the VLG_GEMM_BK environment variable sets the initial value) */
+void vlg_debug_set_conv_probe(unsigned long long* buf);
+/* force the contraction depth per LDS tile of the 128x128 fp32 GEMM kernels (16 | 32; 0 = the library's own choice per
+ * epilogue; the VLG_GEMM_BK environment variable sets the initial value) (tools/ab/gemm_ab.py) */
 void vlg_debug_set_gemm_bk(int bk);
-/* diagnostic only: consecutive N tiles per block of the chained fp32 GEMM path (0 = never chain, -1 = the library's choice;
- * bit 16: chained launches as ping-pong pairs of four-wave groups - measured slower, see csrc/gemm.hip) */
+/* consecutive N tiles per block of the chained fp32 GEMM path (0 = never chain, -1 = the library's choice; bit 16: chained
+ * launches as ping-pong pairs of four-wave groups - measured slower, see csrc/gemm.hip) */
 void vlg_debug_set_gemm_run(int run);
+#endif
 
 /* ------------------------------------------------------------------ embedding
  * Object-slot embedding.  SELF-ORACLE; lookup semantics = nn.Embedding row gather

@@ -12,6 +12,7 @@ from conftest import ROOT
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "vlg_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef VLG_DIAG.*?#endif", "", text, flags=re.S)      # diagnostic-build-only entry points
     return sorted(set(re.findall(r"\b(vlg_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -51,3 +52,12 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
                 assert "layout_spec" not in src and "vlg_oracle" not in src, os.path.join(dirpath, f)
+
+
+def test_product_library_has_no_debug_setters():
+    """include/vlg_hip.h promises a library without mutable process-wide state: the vlg_debug_set_* switches exist only in
+    the diagnostic build (make diag, -DVLG_DIAG), never in the library the product loads."""
+    from vlg import hip
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in ("vlg_debug_set_clock_probe", "vlg_debug_set_conv_probe", "vlg_debug_set_gemm_bk", "vlg_debug_set_gemm_run"):
+        assert not hasattr(lib, name), name

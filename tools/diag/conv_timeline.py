@@ -19,7 +19,7 @@ hw, cin, cout = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sy
 b = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 mode = sys.argv[5] if len(sys.argv) > 5 else "fwd"          # fwd | dgrad | wgrad
 dev = torch.device("cuda:0")
-lib = hip.load()
+lib = hip.require_diag()
 raw = ctypes.CDLL(hip.LIB_PATH)
 raw.vlg_debug_set_conv_probe.argtypes = [ctypes.c_void_p]
 ptr = lambda t: t.data_ptr()

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "video-layout-generation_amd")]
 import torch
 from vlg import hip
-lib = hip.load()
+lib = hip.require_diag()
 dev = torch.device("cuda:0")
 M, d = 32768, 256
 ff = 4 * d

@@ -15,7 +15,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "video-layout-generation_amd")]
 import torch
 from vlg import hip
 from vlg.hip import EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID
-lib = hip.load()
+lib = hip.require_diag()
 dev = torch.device("cuda:0")
 M, d = 32768, 256
 ff = 4 * d

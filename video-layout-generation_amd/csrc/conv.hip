@@ -876,8 +876,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_first_kernel(const float
 }
 
 #ifdef VLG_TIMELINE
+#ifdef VLG_DIAG          /* diagnostic build only (csrc/gemm.hip): the product library keeps no mutable process-wide state */
 static unsigned long long* vlg_conv_probe = nullptr;
 extern "C" void vlg_debug_set_conv_probe(unsigned long long* p) { vlg_conv_probe = p; }
+#else
+static constexpr unsigned long long* vlg_conv_probe = nullptr;
+#endif
 #endif
 template <int MODE, int BM, int BN, int BK = 32>
 static int launch_conv(ConvArgs g, hipStream_t s) {

@@ -638,15 +638,23 @@ __global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (BM == 64 && 
     }
 }
 
-// diagnostic: a device buffer of 2 * blocks uint64 set through vlg_debug_set_clock_probe (NULL = off)
+// The library keeps NO mutable process-wide state (include/vlg_hip.h).  The development switches below exist only in the
+// diagnostic build (`make diag` -> libvlg_hip_diag.so, -DVLG_DIAG; loaded by tools/diag, tools/ab through VLG_HIP_LIB); in
+// the product build they are constants and the vlg_debug_set_* entry points do not exist.
+#ifdef VLG_DIAG
+// a device buffer of 2 * blocks uint64 set through vlg_debug_set_clock_probe (NULL = off)
 static unsigned long long* vlg_gemm_clock_probe = nullptr;
 extern "C" void vlg_debug_set_clock_probe(unsigned long long* p) { vlg_gemm_clock_probe = p; }
+#else
+static constexpr unsigned long long* vlg_gemm_clock_probe = nullptr;
+#endif
 
 // Contraction depth per tile.  Measured on MI355X at the metric shape (tools/kernel_bench.py):
 // BK = 32 (2 blocks / CU) is 3-5 % faster for plain epilogues, BK = 16 (41 KB LDS, 4 blocks / CU)
 // is 8-11 % faster when the epilogue is heavy (GELU / dGELU: two extra 134 MB streams), because more
 // resident blocks de-synchronise the store bursts from the other blocks' MFMA phases.
 // VLG_GEMM_BK=16|32 forces one value for A/B runs.
+#ifdef VLG_DIAG
 static int vlg_gemm_bk_forced = -1;
 static int gemm_bk_override() {
     if (vlg_gemm_bk_forced < 0) {
@@ -656,10 +664,17 @@ static int gemm_bk_override() {
     return vlg_gemm_bk_forced;
 }
 extern "C" void vlg_debug_set_gemm_bk(int bk) { vlg_gemm_bk_forced = (bk == 16 || bk == 32) ? bk : 0; }
+#else
+static int gemm_bk_override() {                  // the environment variable, read once: configuration, not state
+    static const int forced = [] { const char* e = getenv("VLG_GEMM_BK"); return e ? atoi(e) : 0; }();
+    return forced;
+}
+#endif
 
 // Consecutive N tiles per block (GemmArgs::run) for a launch that would otherwise take several rounds of blocks: the
 // largest divisor of the N tile count that still leaves one block per slot.  Only where EVERY block takes the fast path
 // (no edge tiles, an even number of K tiles, 32-bit spans): a block that does not computes one tile only.
+#ifdef VLG_DIAG
 static int vlg_gemm_run_forced = -1;
 static int vlg_gemm_pingpong = 0;
 // run: 0 = never chain, -1 = the library's choice, > 0 = that many; bit 16 set: chained launches as ping-pong pairs (two
@@ -669,6 +684,9 @@ extern "C" void vlg_debug_set_gemm_run(int run) {
     vlg_gemm_pingpong = (run >= 0 && (run & 0x10000)) ? 1 : 0;
     vlg_gemm_run_forced = run < 0 ? -1 : (run & 0xffff) == 0xffff ? -1 : (run & 0xffff);
 }
+#else
+static constexpr int vlg_gemm_run_forced = -1;
+#endif
 template <int BM, int BN, int BK, bool A_KC, bool B_KC>
 static int gemm_run(const GemmArgs& g, int slots) {
     if (BM != 128 || BN != 128 || g.splits != 1) return 1;
@@ -748,10 +766,12 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
     if constexpr (CAN_RUN) {
         // chained launches: two four-wave groups per workgroup taking the matrix pipe in turns (see the kernel); the virtual
         // block ids of a group must keep their XCD (multiple of 8 workgroups)
+#ifdef VLG_DIAG
         if (g.run > 1 && vlg_gemm_pingpong && (blocks % 16) == 0) {
             hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM, true>), dim3((unsigned)(blocks / 2)), dim3(2 * GEMM_THREADS), 0, s, g);
             return vlg_last_error();
         }
+#endif
     }
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, A_KC, B_KC, EPI, COLSUM>), dim3((unsigned)blocks), block, 0, s, g);
     return vlg_last_error();

@@ -25,9 +25,6 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "vlg_abi_version": (I, []),
     "vlg_build_arch": (c_char_p, []),
-    "vlg_debug_set_clock_probe": (None, [P]),
-    "vlg_debug_set_gemm_bk": (None, [I]),
-    "vlg_debug_set_gemm_run": (None, [I]),
     "vlg_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "vlg_embed_bwd_slabs": (I, []),
     "vlg_embed_bwd_slabs_for": (I, [I, I, I, I, I]),
@@ -85,6 +82,13 @@ SIGNATURES = {
     "vlg_add_rows": (I, [P, P, L, I, P]),
     "vlg_sum_partials": (I, [P, I, P, I, P]),
 }
+# entry points of the DIAGNOSTIC build only (make -C csrc diag; VLG_HIP_LIB=.../libvlg_hip_diag.so): typed when present
+DIAG_SIGNATURES = {
+    "vlg_debug_set_clock_probe": (None, [P]),
+    "vlg_debug_set_conv_probe": (None, [P]),
+    "vlg_debug_set_gemm_bk": (None, [I]),
+    "vlg_debug_set_gemm_run": (None, [I]),
+}
 CEPI_BIAS, CEPI_RESID, CEPI_PRELU, CEPI_DPRELU, CEPI_ACCUM, CEPI_CIN4 = 1, 2, 4, 8, 16, 32
 
 _lib = None
@@ -112,7 +116,21 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DIAG_SIGNATURES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
+    return lib
+
+
+def require_diag() -> ctypes.CDLL:
+    """Development tools only: the diagnostic build of the library (vlg_debug_set_* switches)."""
+    lib = load()
+    if not hasattr(lib, "vlg_debug_set_clock_probe"):
+        raise HipError("this tool needs the diagnostic build: `make -C video-layout-generation_amd/csrc diag` and run with "
+                       "VLG_HIP_LIB=<repo>/video-layout-generation_amd/libvlg_hip_diag.so (the product library has no debug switches)")
     return lib
 
 
