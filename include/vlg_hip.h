@@ -140,6 +140,14 @@ int vlg_linear_wgrad_slabs_for(int64_t M, int N, int K, int flags);  /* slab cou
 int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
                      float* slabs, int64_t slab_stride, int64_t slab_capacity,
                      int64_t M, int N, int K, int flags /* VLG_EPI_BF16 | storage bits */, void* stream);
+/* vlg_linear_wgrad and vlg_linear_dgrad of ONE projection (same dY) as one call - and, for native fp32 tensors where it pays
+ * (few tokens: neither product fills the chip alone), as ONE launch whose blocks are dealt both problems at once; results
+ * are bit for bit those of the two calls.  epilogue: VLG_EPI_NONE | VLG_EPI_MUL (+ VLG_EPI_BF16 / VLG_EPI_SPLIT3 with fp32
+ * storage: two launches).  Replaces the two autograd nodes of one nn.Linear backward. */
+int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, int ldw, void* dX, int ldx, const void* aux_in,
+                           const void* X, int ldxx, float* slabs, int64_t slab_stride, int64_t slab_capacity,
+                           int64_t M, int N, int K, int epilogue, void* stream);
+
 
 /* ------------------------------------------------------------------- attention
  * Temporal encoder core: causal softmax attention along T for each (clip, slot,

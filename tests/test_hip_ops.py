@@ -213,6 +213,42 @@ def test_linear_gelu_grad_saved_and_mul(H, dev, M, N, K):
     assert lib.vlg_linear_dgrad(dyd.data_ptr(), K2, w2d.data_ptr(), N, du.data_ptr(), N, 0, M, K2, N, H.EPI_MUL, stream()) == 1001
 
 
+@pytest.mark.parametrize("M,N,K,mul", [(4096, 256, 1024, True), (4096, 1024, 256, False), (4096, 256, 256, False), (4096, 768, 256, False),
+                                       (2048, 256, 256, False), (1000, 192, 320, True), (32768, 256, 256, False)])
+def test_linear_dgrad_wgrad_is_the_two_calls(H, dev, M, N, K, mul):
+    """vlg_linear_dgrad_wgrad = vlg_linear_wgrad + vlg_linear_dgrad of one projection, bit for bit - as one launch on 64x64
+    tiles at few tokens (the strong-scaling shard: M = 4 096; ragged M / N / K included), as two launches elsewhere -
+    and right against fp64."""
+    lib = H.load()
+    torch.manual_seed(M + N)
+    dy, w, x = torch.randn(M, N), torch.randn(N, K) / math.sqrt(K), torch.randn(M, K)
+    aux = torch.randn(M, K) if mul else None
+    dyd, wd, xd = dy.to(dev), w.to(dev), x.to(dev)
+    auxd = aux.to(dev) if mul else None
+    epi = H.EPI_MUL if mul else H.EPI_NONE
+    ns = lib.vlg_linear_wgrad_slabs_for(M, N, K, 0)
+    L = N * K + N
+    out = []
+    for fused in (False, True):
+        slabs = torch.full((ns * L,), float("nan"), device=dev)
+        dx = torch.full((M, K), float("nan"), device=dev)
+        if fused:
+            H.call("vlg_linear_dgrad_wgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, H.ptr(auxd), xd.data_ptr(), K,
+                   slabs.data_ptr(), L, slabs.numel(), M, N, K, epi, stream())
+        else:
+            H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), L, slabs.numel(), M, N, K, 0, stream())
+            H.call("vlg_linear_dgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, H.ptr(auxd), M, N, K, epi, stream())
+        out.append((dx, reduce_slabs(H, slabs, L, ns, L, dev)))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    want_dx = dy.double() @ w.double()
+    if mul:
+        want_dx = want_dx * aux.double()
+    assert_close(out[1][0], want_dx.float(), rtol=1e-4, atol=1e-4, what="paired dgrad")
+    g = out[1][1].cpu()
+    assert_close(g[:N * K].view(N, K), (dy.double().t() @ x.double()).float(), rtol=1e-4, atol=2e-3, what="paired wgrad")
+    assert_close(g[N * K:], dy.double().sum(0).float(), rtol=1e-4, atol=1e-3, what="paired bias gradient")
+
+
 def test_linear_chained_tiles(H, dev):
     """Multi-round launches: a block computes a run of N tiles back to back (the K loop continues into the next tile).
     1024 tiles here -> runs of two; forward with bias, forward with GELU + saved derivative, data gradient with the

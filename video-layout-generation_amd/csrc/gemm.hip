@@ -87,8 +87,14 @@ __device__ __forceinline__ void vlg_epi_pace(int issued) {
 // younger every iteration, the two take the matrix pipe in turns, and one group's epilogue (cut into four slices, a
 // barrier each) always runs beside the other group's main loop.  Both groups execute the same number of barriers: the
 // second group starts with nk / 2 empty slots, the first ends with them.
+// LDS floats of one four-wave group: both operand tiles, double-buffered
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
+constexpr int gemm_smem_floats() { return 2 * (Tile<BM, A_KC, BK>::FLOATS + Tile<BN, B_KC, BK>::FLOATS); }
+
+// The kernel body as a device function of (arguments, LDS, block number, block count): gemm_f32_kernel runs one problem per
+// launch, gemm_pair_kernel two independent ones (a projection's data gradient and weight gradient) side by side.
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool PP = false>
-__global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : (BK == 16 ? 3 : 2)) void gemm_f32_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, float* const smem_all, const int blk, const int nblk) {
     // Raised priority until the main loop starts.  It does NOT get this block's vector instructions past an older block's
     // MFMA stream (the vector ALU serves the oldest wave that has a matrix or vector instruction ready, whatever s_setprio
     // says: tools/micro/mfma_f32_valu_share.hip prio / two), but the prologue's loads and LDS writes are issued ahead of the
@@ -106,8 +112,7 @@ __global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (BM == 64 && 
     constexpr int NCH = BK / 8;                    // 8-deep MFMA chunks per tile
     using TA = Tile<BM, A_KC, BK>;
     using TB = Tile<BN, B_KC, BK>;
-    constexpr int SMEM_FLOATS = 2 * (TA::FLOATS + TB::FLOATS);
-    __shared__ __attribute__((aligned(16))) float smem_all[(PP ? 2 : 1) * SMEM_FLOATS];
+    constexpr int SMEM_FLOATS = gemm_smem_floats<BM, BN, BK, A_KC, B_KC>();
     const int grp = PP ? (int)(threadIdx.x >> 8) : 0;          // ping-pong: which of the two four-wave groups
     float* const smem = smem_all + grp * SMEM_FLOATS;
     float* const As0 = smem;                       // As[buf] = As0 + buf * TA::FLOATS
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (BM == 64 && 
     // XCD-aware remap: hardware deals blocks round-robin over 8 XCDs; give each XCD a
     // contiguous run of logical tiles (bijective for any grid size)
     // (ping-pong: the second group takes the upper half of the virtual block ids, so id & 7 still says which XCD)
-    const int nwg = (PP ? 2 : 1) * (int)gridDim.x, bid = (int)blockIdx.x + grp * (int)gridDim.x;
+    const int nwg = (PP ? 2 : 1) * nblk, bid = blk + grp * nblk;
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     // N tiles per block: the fast path of the BK = 32 kernels without bias-gradient sums (the host sets it); a compile-time 1
@@ -638,6 +643,30 @@ __global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (BM == 64 && 
     }
 }
 
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool PP = false>
+__global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : (BK == 16 ? 3 : 2)) void gemm_f32_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem_all[(PP ? 2 : 1) * gemm_smem_floats<BM, BN, BK, A_KC, B_KC>()];
+    gemm_f32_body<BM, BN, BK, A_KC, B_KC, EPI, COLSUM, PP>(g, smem_all, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// A projection's data gradient dX = dY . W and weight gradient dW = dY^T . X need nothing from each other: ONE launch runs
+// both (blocks [0, nd_pad) the data gradient - nd of them real, padded to a multiple of 8 so that a block's number mod 8
+// still names its XCD for the second problem - the rest the weight gradient).  Each problem's blocks execute exactly the code
+// of its own launch (same tiles, same split plan, same sums: bit for bit the two launches), but the chip is dealt both at
+// once: launches that cannot fill 256 CUs on their own (few tokens per GPU: the strong-scaling shard) share it, and one
+// launch ramp / drain is paid instead of two.
+template <int BT, int EPI_D>
+__global__ __launch_bounds__(GEMM_THREADS, BT == 64 ? 4 : 2) void gemm_pair_kernel(const GemmArgs gd, const GemmArgs gw, const int nd, const int nd_pad) {
+    constexpr int FD = gemm_smem_floats<BT, BT, 32, true, false>(), FW = gemm_smem_floats<BT, BT, 32, false, false>();
+    __shared__ __attribute__((aligned(16))) float smem_all[FD > FW ? FD : FW];
+    const int b = (int)blockIdx.x;
+    if (b < nd_pad) {
+        if (b < nd) gemm_f32_body<BT, BT, 32, true, false, EPI_D, false>(gd, smem_all, b, nd);
+    } else {
+        gemm_f32_body<BT, BT, 32, false, false, VLG_EPI_NONE, true>(gw, smem_all, b - nd_pad, (int)gridDim.x - nd_pad);
+    }
+}
+
 // The library keeps NO mutable process-wide state (include/vlg_hip.h).  The development switches below exist only in the
 // diagnostic build (`make diag` -> libvlg_hip_diag.so, -DVLG_DIAG; loaded by tools/diag, tools/ab through VLG_HIP_LIB); in
 // the product build they are constants and the vlg_debug_set_* entry points do not exist.
@@ -944,4 +973,59 @@ extern "C" int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
     if (small) return launch_gemm<64, 64, false, false, VLG_EPI_NONE, true>(g, s);
     return N <= 32 ? launch_gemm<32, 128, false, false, VLG_EPI_NONE, true>(g, s)
                    : launch_gemm<128, 128, false, false, VLG_EPI_NONE, true>(g, s);
+}
+
+// ---- data gradient + weight gradient of one projection in ONE launch (gemm_pair_kernel)
+// VLG_GEMM_PAIR (read once): 0 = always two launches, 1 = one launch where both problems take the 64x64 tiles (few tokens:
+// neither fills the chip alone), 2 = also on 128x128 tiles.
+static int gemm_pair_mode() {
+    static const int mode = [] { const char* e = getenv("VLG_GEMM_PAIR"); return e ? atoi(e) : 1; }();
+    return mode;
+}
+template <int BT, int EPI_D>
+static int launch_pair(GemmArgs gd, GemmArgs gw, hipStream_t s) {
+    gd.tiles_m = (int)((gd.M + BT - 1) / BT); gd.tiles_n = (gd.N + BT - 1) / BT; gd.run = 1; gd.clock_probe = nullptr;
+    gw.tiles_m = (int)((gw.M + BT - 1) / BT); gw.tiles_n = (gw.N + BT - 1) / BT; gw.run = 1; gw.clock_probe = nullptr;
+    if constexpr (BT == 128) gd.run = gemm_run<128, 128, 32, true, false>(gd, 512);
+    const int64_t nd = (int64_t)gd.tiles_m * (gd.tiles_n / gd.run), nw = (int64_t)gw.tiles_m * gw.tiles_n * gw.splits;
+    const int64_t nd_pad = (nd + 7) / 8 * 8;
+    if (nd < 1 || nw < 1 || nd_pad + nw > 0x7fffffff) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL((gemm_pair_kernel<BT, EPI_D>), dim3((unsigned)(nd_pad + nw)), dim3(GEMM_THREADS), 0, s, gd, gw, (int)nd, (int)nd_pad);
+    return vlg_last_error();
+}
+
+extern "C" int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, int ldw, void* dX, int ldx, const void* aux_in,
+                                      const void* X, int ldxx, float* slabs, int64_t slab_stride, int64_t slab_capacity,
+                                      int64_t M, int N, int K, int epilogue, void* stream) {
+    // dX[M,K] = dY[M,N] . W[N,K] (x aux_in with VLG_EPI_MUL)   and   slab[s] = dY^T . X, column sums of dY  - the results of
+    // vlg_linear_wgrad followed by vlg_linear_dgrad with the same arguments, bit for bit
+    const bool native = (epilogue & ~VLG_EPI_MUL) == 0;
+    bool small_w = false;
+    int splits = 1; int64_t per = 0;
+    if (native && gemm_pair_mode() > 0 && M >= 1 && N >= 4 && K >= 4) wgrad_plan(M, N, K, &splits, &per, false, &small_w);
+    const bool small_d = gemm_wants_small(M, K, 1);
+    const bool pair = native && gemm_pair_mode() > 0 && small_w == small_d && (small_d || gemm_pair_mode() > 1) && N > 32 && K > 32;
+    if (!pair) {
+        const int wflags = epilogue & (VLG_EPI_BF16 | VLG_EPI_SPLIT3 | VLG_EPI_A_BF16 | VLG_EPI_B_BF16);
+        // (storage bits of the pair's three activation operands differ per call: callers with bf16 storage use the two entry points)
+        if (epilogue & (VLG_EPI_A_BF16 | VLG_EPI_B_BF16 | VLG_EPI_OUT_BF16)) return VLG_ERR_SHAPE;
+        const int rc = vlg_linear_wgrad(dY, ldy, X, ldxx, slabs, slab_stride, slab_capacity, M, N, K, wflags, stream);
+        if (rc != 0) return rc;
+        return vlg_linear_dgrad(dY, ldy, W, ldw, dX, ldx, aux_in, M, N, K, epilogue, stream);
+    }
+    if ((N & 3) || (K & 3) || ldy < N || ldw < K || ldx < K || ldxx < K) return VLG_ERR_SHAPE;
+    if (!gemm_ptr_ok(dY, ldy) || !gemm_ptr_ok(W, ldw) || !gemm_ptr_ok(X, ldxx) || !dX || !slabs) return VLG_ERR_ALIGN;
+    if ((epilogue & VLG_EPI_MUL) && !aux_in) return VLG_ERR_SHAPE;
+    if (slab_stride < (int64_t)N * K + N || slab_capacity < (int64_t)splits * slab_stride) return VLG_ERR_SHAPE;
+    GemmArgs gd{}, gw{};
+    gd.A = dY; gd.B = W; gd.C = dX; gd.aux_in = aux_in;
+    gd.M = M; gd.N = K; gd.Kc = N; gd.lda = ldy; gd.ldb = ldw; gd.ldc = ldx;
+    gd.splits = 1; gd.kc_per_split = N;
+    gw.A = dY; gw.B = X; gw.C = slabs;
+    gw.M = N; gw.N = K; gw.Kc = M; gw.lda = ldy; gw.ldb = ldxx; gw.ldc = K;
+    gw.splits = splits; gw.kc_per_split = per; gw.slab_stride = slab_stride; gw.colsum_off = (int64_t)N * K;
+    hipStream_t s = (hipStream_t)stream;
+    const bool mul = (epilogue & VLG_EPI_MUL) != 0;
+    if (small_d) return mul ? launch_pair<64, VLG_EPI_MUL>(gd, gw, s) : launch_pair<64, VLG_EPI_NONE>(gd, gw, s);
+    return mul ? launch_pair<128, VLG_EPI_MUL>(gd, gw, s) : launch_pair<128, VLG_EPI_NONE>(gd, gw, s);
 }

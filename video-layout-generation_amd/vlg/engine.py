@@ -215,6 +215,10 @@ class LayoutEngine:
         # gradients + two layer-norms) write side by side into ONE arena and ONE table-driven launch (vlg_reduce_slabs_table,
         # the form the GridNet path uses) reduces them all when the bucket is complete: 27 launches of ~5.5 us -> 6 per step.
         self.group_reduce = os.environ.get("VLG_GROUP_REDUCE", "1") == "1" and not self.overlap_wgrad and not self.overlap_small
+        # a projection's data gradient and weight gradient through one call (one launch at few tokens): fp32 tensors, single
+        # stream; the library decides per shape (VLG_GEMM_PAIR)
+        self.pair_backward = (not self.bf16_store and not self.overlap_wgrad and not self.overlap_small and not self.gelu_on_load
+                              and self.precision == "fp32" and os.environ.get("VLG_PAIR_BACKWARD", "1") == "1")
         if self.group_reduce:
             pad = lambda v: (v + 3) // 4 * 4
             layer = sum(pad(v) for v in need[2:6]) + 2 * pad(need[1])
@@ -310,6 +314,20 @@ class LayoutEngine:
         self._timed("gemm_wgrad" if N > 32 else "gemm_head", 2.0 * M * N * K, "vlg_linear_wgrad", ptr(dy), N, ptr(x),
                     K, ptr(arena), stride, arena.numel(), M, N, K, self.gemm_flags | self._storage_bits(dy, x) | extra, s,
                     nbytes=dy.element_size() * M * N + x.element_size() * M * K + 4.0 * n_slabs * stride)
+        self._reduce("w", stride, n_slabs, self.layout[wname][0], stride)
+
+    def _dgrad_wgrad(self, dy, w, dx, x, wname, M, N, K, epi=EPI_NONE, aux_in=None):
+        """backward of one projection y = x W^T + b given dy: grad[w | b] (slab partials -> flat gradient) AND dx = dy . W
+        (x aux_in with EPI_MUL) through ONE C-ABI call, which the library runs as one launch where neither product fills
+        the chip alone (few tokens per GPU; vlg_linear_dgrad_wgrad).  Same results, bit for bit, as _wgrad then _dgrad."""
+        lib = hip.load()
+        stride = N * K + N
+        n_slabs = lib.vlg_linear_wgrad_slabs_for(M, N, K, self.gemm_flags)
+        arena = self._arena("w", n_slabs * stride)
+        nb = (dy.element_size() * M * N * 2 + w.element_size() * N * K + dx.element_size() * M * K * (1 + (aux_in is not None)) +
+              x.element_size() * M * K + 4.0 * n_slabs * stride)
+        self._timed("gemm_pair", 4.0 * M * N * K, "vlg_linear_dgrad_wgrad", ptr(dy), N, ptr(w), K, ptr(dx), K, ptr(aux_in),
+                    ptr(x), K, ptr(arena), stride, arena.numel(), M, N, K, epi | self.gemm_flags, self._stream(), nbytes=nb)
         self._reduce("w", stride, n_slabs, self.layout[wname][0], stride)
 
     def _ln_fwd(self, x, gname, y, stat, M):
@@ -447,6 +465,19 @@ class LayoutEngine:
             return
         for l in reversed(range(L)):
             pre = "l%d." % l
+            if self.pair_backward and self._pair_shapes(M):
+                self._dgrad_wgrad(self.dx, self.pw(pre + "ff2_w"), self.du, self.gl[l], pre + "ff2_w", M, d, ff, self._epi_dff2, aux_in=self.u[l])
+                self._dgrad_wgrad(self.du, self.pw(pre + "ff1_w"), self.dh, self.h2[l], pre + "ff1_w", M, ff, d)
+                self._ln_bwd(self.dh, self.xmid[l], self.stats[2 * l + 1], pre + "ln2_g", self.dx, self.dx, M)
+                self._dgrad_wgrad(self.dx, self.pw(pre + "proj_w"), self.dh, self.att[l], pre + "proj_w", M, d, d)
+                self._timed("attn_bwd", 0.0, "vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s,
+                            nbytes=7.0 * self.qkv.element_size() * M * d)
+                self._dgrad_wgrad(self.dqkv, self.pw(pre + "qkv_w"), self.dh, self.h1[l], pre + "qkv_w", M, 3 * d, d)
+                self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)
+                self._join_reduces()
+                if reducer is not None:
+                    reducer.ready("l%d" % l)
+                continue
             # FFN:  x_out = xmid + W2 gelu(W1 h2 + b1) + b2
             if self.gelu_on_load:
                 on_side(("dx",), lambda: self._wgrad(self.dx, self.u[l], pre + "ff2_w", M, d, ff, extra=EPI_ACT_GELU))
@@ -475,6 +506,12 @@ class LayoutEngine:
                 reducer.ready("l%d" % l)
         join()
         self._backward_tail(batch, B, T, N, M, reducer)
+
+    def _pair_shapes(self, M: int) -> bool:
+        """the paired backward is taken where the library fuses the launches (few tokens); elsewhere the separate calls keep
+        the per-kernel timing families of bench.py meaningful (VLG_GEMM_PAIR=2 pairs every shape)"""
+        mode = int(os.environ.get("VLG_GEMM_PAIR", "1"))
+        return mode >= 2 or (mode == 1 and M <= 16384)
 
     def _backward_tail(self, batch, B, T, N, M, reducer) -> None:
         cfg, d = self.cfg, self.cfg.d
