@@ -608,9 +608,17 @@ def main():
                 e4.train_step(b4)
             dt = timed_steps(lambda: e4.train_step(b4), 30)
             f4 = step_flops(c4)
+            run4 = e4.capture_train_step(b4)                       # the same step replayed from one hipGraph (one host call)
+            for _ in range(5):
+                run4(b4)
+            dtg = timed_steps(lambda: run4(b4), 30)
             line["strong_scaling_shard"] = {
                 "clips_per_gpu": c4.B, "ms_per_step": round(1e3 * dt, 4), "clips_per_s_one_gpu": round(c4.B / dt, 1),
                 "step_tflops": round(f4["fwd_bwd"] / dt / 1e12, 2),
+                "frac": round(f4["fwd_bwd"] / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "peak": PEAK_F32_MFMA_TFLOPS,
+                "hipgraph_ms_per_step": round(1e3 * dtg, 4),
+                "kernels": "64x64-tile fp32 MFMA GEMMs (launches whose 128x128 tiles leave CUs empty), data + weight gradient of a "
+                           "projection in one launch (gemm_pair_kernel)",
                 "note": "one rank's share if the GLOBAL batch stayed 32 on 8 GPUs (reference semantics); no communication here: "
                         "the 12.7 MB gradient all-reduce would have to hide inside this step time"}
             del e4
