@@ -630,6 +630,33 @@ def main():
                 "note": "one rank's share if the GLOBAL batch stayed 32 on 8 GPUs (reference semantics); no communication here: "
                         "the 12.7 MB gradient all-reduce would have to hide inside this step time"}
             del e4
+            # informational, SELF-ORACLE: the same step with the per-clip reading of the temporal encoder (attention = "clip":
+            # block-causal attention over all T*N tokens of a clip on fp32 MFMA flash-style kernels, csrc/attention_clip.hip)
+            cc = LayoutConfig(B=cfg.B, T=cfg.T, N=cfg.N, d=cfg.d, n_layers=cfg.n_layers, attention="clip")
+            e6 = LayoutEngine(cc, dev, seed=SEED, padded_slots=False)
+            for _ in range(3):
+                e6.train_step(batch)
+            dt = timed_steps(lambda: e6.train_step(batch), 10)
+            e6.timer = KernelTimer(only=("attn_clip_fwd", "attn_clip_bwd"))
+            e6.train_step(batch)
+            e6.train_step(batch)
+            torch.cuda.synchronize()
+            ks = e6.timer.summary()
+            e6.timer = None
+            f6 = step_flops(cc)
+            line["per_clip_attention"] = {
+                "value": round(cfg.B / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt, 4),
+                "step_gflop": round(f6["fwd_bwd"] / 1e9, 1), "step_tflops": round(f6["fwd_bwd"] / dt / 1e12, 2),
+                "frac": round(f6["fwd_bwd"] / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "kernels": {k: {"avg_launch_us": round(1e3 * v["avg_ms"], 2), "gflop_per_launch": round(v["flops_per_launch"] / 1e9, 2),
+                                "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 2),
+                                "frac_of_fp32_mfma_peak": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                            for k, v in ks.items()},
+                "self_oracle_hyperparameters": cc.describe()["attention"], "final_loss": round(float(e6.loss_out[0]), 5),
+                "note": "SELF-ORACLE option (VLG_ATTENTION=clip), not the headline: token (t, n) attends to every slot of frames <= t "
+                        "of its clip; attn_clip_bwd = two launches (query owner dQ, key owner dK / dV), algorithmic flops = visible "
+                        "(query, key) pairs x 4 x 64 x {1 fwd, 2.5 bwd}"}
+            del e6
             if not distributed:
                 line["rccl_world1"] = rccl_world1_leg(cfg, dev, batch, args.steps)
             if not args.no_reference_step:

@@ -176,6 +176,19 @@ int vlg_layout_loss(const float* out, int ld, const int64_t* tgt_class, const fl
                     int B, int T, int N, int n_classes, float beta, float iou_eps,
                     float w_reg, float w_iou, float w_ce, void* stream);
 
+/* ------------------------------------------------------------------ per-clip attention (option attention = "clip")
+ * Block-causal softmax attention over ALL T*N tokens of a clip, per (clip, head): token (t, n) attends to every slot of
+ * frames <= t; slots with valid == 0 (valid may be NULL: none) are never keys, except for themselves.  SELF-ORACLE
+ * (oracle/layout_spec.py:clip_attention) - the reference has no attention; this is the "per-clip tile" reading of
+ * BASELINE.json's temporal encoder next to the per-slot default (vlg_attention_fwd / _bwd).  fp32, head dim 64, T*N a multiple
+ * of 32.  qkv [B*N*T, 3d] / out, dout [B*N*T, d] in the internal row order; valid (B,T,N) floats in the public order;
+ * lse and delta: B * (d/64) * T*N floats each (log-sum-exp in the log2 domain, written by fwd; <dO, O>, scratch of bwd).
+ * bwd = two launches (query owner: dQ; key owner: dK, dV): every gradient element has one owner, no atomics. */
+int vlg_attention_clip_fwd(const float* qkv, const float* valid, float* out, float* lse,
+                           int64_t B, int T, int N, int d, void* stream);
+int vlg_attention_clip_bwd(const float* qkv, const float* valid, const float* out, const float* dout, const float* lse,
+                           float* delta, float* dqkv, int64_t B, int T, int N, int d, void* stream);
+
 /* ------------------------------------------------------------------ reductions */
 int vlg_reduce_slabs(const float* slabs, int64_t slab_stride, int n_slabs,
                      float* dst, int64_t len, void* stream);

@@ -109,11 +109,41 @@ def temporal_attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
     return o.permute(0, 3, 1, 2, 4).reshape(B, T, N, d)
 
 
-def encoder_layer(p, pre: str, x: torch.Tensor, n_heads: int) -> torch.Tensor:
+def clip_attention(qkv: torch.Tensor, n_heads: int, valid: torch.Tensor = None) -> torch.Tensor:
+    """Block-causal attention over ALL T*N tokens of a clip, per (clip, head) - the "per-clip tile" reading of
+    BASELINE.json's temporal encoder (SELF-ORACLE: the reference has no attention at all; option attention="clip").
+
+    Token (t, n) attends to every token (t', n') of the same clip with t' <= t: all slots of its own and of every
+    earlier frame (slots exchange information, the future stays hidden).  Padded slots (valid == 0, variable-N
+    batches) are never attended to - except by themselves, so that every softmax row has a key.
+    qkv: (B,T,N,3d), valid: (B,T,N) 0/1 floats or None.  Returns (B,T,N,d)."""
+    B, T, N, d3 = qkv.shape
+    d = d3 // 3
+    hd = d // n_heads
+    S = T * N
+    q, k, v = qkv.split(d, dim=-1)
+
+    def heads(t):  # (B,T,N,d) -> (B,H,S,hd), tokens frame-major: s = t*N + n
+        return t.reshape(B, S, n_heads, hd).permute(0, 2, 1, 3)
+
+    q, k, v = heads(q), heads(k), heads(v)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)        # (B,H,S,S)
+    frame = torch.arange(S) // N
+    allowed = (frame[None, :] <= frame[:, None])[None, None]        # key frame <= query frame
+    if valid is not None:
+        allowed = allowed & (valid.reshape(B, 1, 1, S) > 0)
+    allowed = allowed | torch.eye(S, dtype=torch.bool)[None, None]
+    s = s.masked_fill(~allowed, float("-inf"))
+    a = torch.softmax(s, dim=-1)
+    o = torch.matmul(a, v)                                          # (B,H,S,hd)
+    return o.permute(0, 2, 1, 3).reshape(B, T, N, d)
+
+
+def encoder_layer(p, pre: str, x: torch.Tensor, n_heads: int, attention: str = "slot", valid=None) -> torch.Tensor:
     d = x.shape[-1]
     h = F.layer_norm(x, (d,), p[pre + "ln1_g"], p[pre + "ln1_b"], LN_EPS)
     qkv = F.linear(h, p[pre + "qkv_w"], p[pre + "qkv_b"])
-    o = temporal_attention(qkv, n_heads)
+    o = clip_attention(qkv, n_heads, valid) if attention == "clip" else temporal_attention(qkv, n_heads)
     x = x + F.linear(o, p[pre + "proj_w"], p[pre + "proj_b"])
     h = F.layer_norm(x, (d,), p[pre + "ln2_g"], p[pre + "ln2_b"], LN_EPS)
     u = F.linear(h, p[pre + "ff1_w"], p[pre + "ff1_b"])
@@ -121,13 +151,14 @@ def encoder_layer(p, pre: str, x: torch.Tensor, n_heads: int) -> torch.Tensor:
     return x
 
 
-def forward(p, slot_class, slot_box, n_layers: int, n_classes: int = 20):
-    """Returns (class logits (B,T,N,C), raw box outputs (B,T,N,4))."""
+def forward(p, slot_class, slot_box, n_layers: int, n_classes: int = 20, attention: str = "slot", valid=None):
+    """Returns (class logits (B,T,N,C), raw box outputs (B,T,N,4)).  attention = "slot" (causal along T per slot, the
+    default) or "clip" (block-causal over all slots of a clip; `valid` masks padded slots as keys)."""
     x = embed(p, slot_class, slot_box)
     d = x.shape[-1]
     n_heads = d // HEAD_DIM
     for l in range(n_layers):
-        x = encoder_layer(p, "l%d." % l, x, n_heads)
+        x = encoder_layer(p, "l%d." % l, x, n_heads, attention, valid)
     x = F.layer_norm(x, (d,), p["lnf_g"], p["lnf_b"], LN_EPS)
     out = F.linear(x, p["head_w"], p["head_b"])
     return out[..., :n_classes], out[..., n_classes:]
@@ -159,10 +190,11 @@ def losses(logits, box_raw, tgt_class, tgt_box, valid):
     return total, l_reg, l_iou, l_ce
 
 
-def loss_and_grads(p, batch, n_layers: int, n_classes: int = 20):
+def loss_and_grads(p, batch, n_layers: int, n_classes: int = 20, attention: str = "slot"):
     """One forward + backward.  Returns (loss parts tuple of floats, {name: grad})."""
     q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    logits, box_raw = forward(q, batch["slot_class"], batch["slot_box"], n_layers, n_classes)
+    logits, box_raw = forward(q, batch["slot_class"], batch["slot_box"], n_layers, n_classes, attention,
+                              batch["valid"] if attention == "clip" else None)
     parts = losses(logits, box_raw, batch["tgt_class"], batch["tgt_box"], batch["valid"])
     parts[0].backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in q.items()}

@@ -33,6 +33,42 @@ def reduce_slabs(H, slabs, stride, n, length, dev):
     return dst
 
 
+# ------------------------------------------------------------------------ per-clip attention (option attention = "clip")
+@pytest.mark.parametrize("B,T,N,d,masked", [(2, 4, 8, 64, False), (2, 4, 8, 64, True), (3, 8, 16, 128, True), (2, 16, 24, 64, True),
+                                              (1, 16, 64, 256, False), (2, 32, 5, 64, True), (1, 4, 40, 64, False)])
+def test_clip_attention_fwd_bwd(H, dev, B, T, N, d, masked):
+    """vlg_attention_clip_fwd / _bwd (block-causal attention over all T*N tokens of a clip, fp32 MFMA, flash-style) against the
+    CPU specification oracle.layout_spec.clip_attention and its autograd (SELF-ORACLE): tiles that straddle frames (N = 5, 24,
+    40: element-wise masks), padded slots as keys (valid == 0: never attended to, except by themselves), several query blocks
+    (T*N = 1024), NaN-prefilled outputs."""
+    torch.manual_seed(B * 1000 + T * N)
+    heads = d // 64
+    qkv = torch.randn(B, T, N, 3 * d) * 0.7
+    valid = (torch.rand(B, T, N) > 0.3).float() if masked else None
+    q = qkv.clone().requires_grad_(True)
+    want = O.clip_attention(q, heads, valid)
+    gy = torch.randn(B, T, N, d)
+    want.backward(gy)
+    M, S = B * T * N, T * N
+    to_rows = lambda t: t.permute(0, 2, 1, 3).contiguous().view(M, t.shape[-1])       # (B,T,N,.) -> internal rows (b, n, t)
+    qd, gd = to_rows(qkv).to(dev), to_rows(gy).to(dev)
+    vd = valid.to(dev) if masked else None
+    out = torch.full((M, d), float("nan"), device=dev)
+    lse = torch.full((B * heads * S,), float("nan"), device=dev)
+    H.call("vlg_attention_clip_fwd", qd.data_ptr(), H.ptr(vd), out.data_ptr(), lse.data_ptr(), B, T, N, d, stream())
+    got = out.view(B, N, T, d).permute(0, 2, 1, 3)
+    assert_close(got, want.detach(), rtol=1e-4, atol=2e-5, what="clip attention fwd")
+    dqkv = torch.full((M, 3 * d), float("nan"), device=dev)
+    delta = torch.full((B * heads * S,), float("nan"), device=dev)
+    H.call("vlg_attention_clip_bwd", qd.data_ptr(), H.ptr(vd), out.data_ptr(), gd.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+           dqkv.data_ptr(), B, T, N, d, stream())
+    gq = dqkv.view(B, N, T, 3 * d).permute(0, 2, 1, 3)
+    scale = float(q.grad.abs().max())
+    assert_close(gq.cpu() / scale, q.grad / scale, rtol=1e-4, atol=2e-5, what="clip attention bwd (dq | dk | dv)")
+    # shapes the tiles cannot hold are refused, not mangled
+    assert H.load().vlg_attention_clip_fwd(qd.data_ptr(), 0, out.data_ptr(), lse.data_ptr(), 1, 3, 5, 64, stream()) == 1001
+
+
 # ------------------------------------------------------------------------ embedding
 @pytest.mark.parametrize("B,T,N,d", [(2, 4, 8, 64), (3, 16, 5, 256), (2, 32, 4, 512),
                                      # widths whose d/4-lane groups straddle 64-lane waves (ADVICE round 2): 48, 96, 80, 112 lanes

@@ -58,6 +58,35 @@ def test_step_matches_oracle(dev, kw, variable_n, precision):
         assert_close(g / scale, grads[name] / scale, rtol=1e-4, atol=2e-5, what="grad " + name)
 
 
+@pytest.mark.parametrize("kw", [dict(B=4, T=4, N=8, d=64, n_layers=2), dict(B=2, T=16, N=12, d=256, n_layers=2),
+                                dict(B=1, T=8, N=64, d=128, n_layers=1)])
+@pytest.mark.parametrize("variable_n", [False, True])
+def test_step_with_per_clip_attention_matches_oracle(dev, kw, variable_n):
+    """Option attention = "clip" (block-causal attention over all slots of a clip, csrc/attention_clip.hip): the whole step
+    against the CPU specification with the same option - losses, outputs, every gradient at 1e-4; with variable_n the padded
+    slots must neither be attended to nor receive anything but their own (masked-out) contribution.  SELF-ORACLE."""
+    from vlg.engine import LayoutEngine
+    from vlg.spec import LayoutConfig, param_shapes
+    cfg = LayoutConfig(attention="clip", **kw)
+    eng = LayoutEngine(cfg, dev, seed=1024, padded_slots=variable_n)
+    p = O.init_params(param_shapes(cfg), seed=1024)
+    batch = O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=11, variable_n=variable_n, min_valid=3)
+    parts, grads = O.loss_and_grads(p, batch, cfg.n_layers, attention="clip")
+    loss = eng.forward_backward(to_dev(batch, dev))
+    assert_close(loss, torch.tensor(parts), rtol=1e-4, atol=1e-6, what="loss parts (clip attention)")
+    logits, box_raw = O.forward(p, batch["slot_class"], batch["slot_box"], cfg.n_layers, attention="clip", valid=batch["valid"])
+    gl, gb = eng.outputs_btn()
+    assert_close(gl, logits, rtol=1e-4, atol=1e-4, what="logits (clip attention)")
+    assert_close(gb, box_raw, rtol=1e-4, atol=1e-4, what="box outputs (clip attention)")
+    for name, g in eng.named_grads().items():
+        scale = max(float(grads[name].abs().max()), 1e-6)
+        assert_close(g / scale, grads[name] / scale, rtol=1e-4, atol=2e-5, what="grad %s (clip attention)" % name)
+    # bitwise reproducible (no atomics anywhere in the two backward kernels), eager and replayed from a hipGraph
+    g1 = eng.grads.clone()
+    eng.forward_backward(to_dev(batch, dev))
+    assert torch.equal(g1, eng.grads)
+
+
 def test_three_adam_steps_track_oracle(dev):
     """Parameters after 3 full steps (new batch each step) track the oracle's.
 

@@ -98,7 +98,9 @@ def layout_config(args) -> LayoutConfig:
     gpus = max(int(getattr(args, "gpus", 1) or 1), 1)
     return LayoutConfig(B=max(int(args.batch_size) // gpus, 1), T=_knob(args, "n_frames", "VLG_FRAMES", 16),
                         N=_knob(args, "n_slots", "VLG_SLOTS", 64), d=_knob(args, "d_model", "VLG_DMODEL", 256),
-                        n_layers=_knob(args, "n_layers", "VLG_LAYERS", 4))
+                        n_layers=_knob(args, "n_layers", "VLG_LAYERS", 4),
+                        # "slot" (default): causal attention along T per slot; "clip": block-causal over all slots of a clip
+                        attention=str(getattr(args, "attention", None) or os.environ.get("VLG_ATTENTION", "slot")))
 
 
 def get_layout_engine(args, cfg: Optional[LayoutConfig] = None, engine_factory: Optional[Callable] = None):
@@ -111,7 +113,8 @@ def get_layout_engine(args, cfg: Optional[LayoutConfig] = None, engine_factory: 
         precision = str(getattr(args, "precision", None) or os.environ.get("VLG_PRECISION", "fp32"))
         engine = LayoutEngine(cfg, device, seed=int(getattr(args, "seed", SEED)),
                               lr=float(getattr(args, "lr", ADAM_LR)), beta1=float(getattr(args, "beta1", ADAM_BETA1)),
-                              precision=precision)
+                              precision=precision,
+                              padded_slots=bool(_knob(args, "variable_n", "VLG_VARIABLE_N", 0)))   # fixed-N feeds hold no padded slots
     else:
         engine = engine_factory(cfg, args)
     ckpt_path = getattr(args, "ckpt", None)

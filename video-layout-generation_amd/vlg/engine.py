@@ -60,7 +60,7 @@ class LayoutEngine:
     """Owns parameters, optimiser state and workspace; runs forward/backward/Adam."""
 
     def __init__(self, cfg: LayoutConfig, device: torch.device, seed: int = 1024,
-                 lr: float = ADAM_LR, beta1: float = ADAM_BETA1, precision: str = "fp32"):
+                 lr: float = ADAM_LR, beta1: float = ADAM_BETA1, precision: str = "fp32", padded_slots: bool = True):
         """precision:
         "fp32"      exact-fp32 MFMA projections, every tensor fp32 (parity 1e-4);
         "bf16"      BASELINE.json configs[2]: bf16 MFMA projections (fp32 accumulate) AND the activations that only
@@ -74,6 +74,11 @@ class LayoutEngine:
         cfg.validate()
         if precision not in ("fp32", "bf16", "bf16_mfma", "fp32x3"):
             raise ValueError("precision must be fp32, fp32x3, bf16 or bf16_mfma")
+        if cfg.attention == "clip" and precision == "bf16":
+            raise ValueError("attention='clip' runs on fp32 tensors (precision fp32 | fp32x3 | bf16_mfma)")
+        # attention = "clip": padded slots (batch['valid'] == 0) must not be attended to; padded_slots = False tells the engine
+        # that its batches never hold any (fixed-N feeds), so the kernels skip the per-key validity masks
+        self.padded_slots = bool(padded_slots)
         self.precision = precision
         self.gemm_flags = {"fp32": 0, "fp32x3": hip.EPI_SPLIT3}.get(precision, hip.EPI_BF16)
         self.bf16_store = precision == "bf16"
@@ -197,6 +202,9 @@ class LayoutEngine:
         self.du = torch.empty(M, ff, **act)
         self.dqkv = torch.empty(M, 3 * d, **act)
         self.loss_scratch = torch.zeros(lib.vlg_layout_loss_scratch(), **f32)
+        if cfg.attention == "clip":       # per query and head: log-sum-exp of every layer (saved for backward), <dO, O> scratch
+            self.lse = torch.empty(L, cfg.n_heads * M, **f32)
+            self.delta = torch.empty(cfg.n_heads * M, **f32)
         # partial-sum ("slab") arenas: floats needed by the embedding, a layer-norm, and each weight-gradient shape
         emb_len = self.layout["l0.ln1_g"][0]
         need = [lib.vlg_embed_bwd_slabs() * emb_len, lib.vlg_layernorm_bwd_slabs(M) * 2 * d]
@@ -210,7 +218,7 @@ class LayoutEngine:
         self.overlap_wgrad = os.environ.get("VLG_OVERLAP_WGRAD", "0") == "1"
         # second option: the bandwidth-bound kernels of backward (layer-norm backward, attention backward) run on the side
         # stream BESIDE the weight-gradient GEMM that does not depend on them (see backward)
-        self.overlap_small = os.environ.get("VLG_OVERLAP_SMALL", "0") == "1"
+        self.overlap_small = os.environ.get("VLG_OVERLAP_SMALL", "0") == "1" and cfg.attention == "slot"
         # Default (VLG_GROUP_REDUCE=1, single-stream backward): the partial-sum producers of one bucket (a layer: four weight
         # gradients + two layer-norms) write side by side into ONE arena and ONE table-driven launch (vlg_reduce_slabs_table,
         # the form the GridNet path uses) reduces them all when the bucket is complete: 27 launches of ~5.5 us -> 6 per step.
@@ -330,6 +338,29 @@ class LayoutEngine:
                     ptr(x), K, ptr(arena), stride, arena.numel(), M, N, K, epi | self.gemm_flags, self._stream(), nbytes=nb)
         self._reduce("w", stride, n_slabs, self.layout[wname][0], stride)
 
+    def _attn_fwd(self, l: int, batch, B, T, N, M) -> None:
+        d, s = self.cfg.d, self._stream()
+        if self.cfg.attention == "clip":
+            S2 = T * N
+            fl = 4.0 * B * d * N * N * T * (T + 1) / 2.0            # visible (query, key) pairs x 2 products x 2 x head dim, all heads
+            self._timed("attn_clip_fwd", fl, "vlg_attention_clip_fwd", ptr(self.qkv[l]), ptr(batch["valid"]) if self.padded_slots else 0,
+                        ptr(self.att[l]), ptr(self.lse[l]), B, T, N, d, s, nbytes=16.0 * M * d)
+            return
+        self._timed("attn_fwd", 0.0, "vlg_attention_fwd" + self._sfx, ptr(self.qkv[l]), ptr(self.att[l]), B * N, T, d, s,
+                    nbytes=4.0 * self.qkv.element_size() * M * d)
+
+    def _attn_bwd(self, l: int, batch, B, T, N, M) -> None:
+        d, s = self.cfg.d, self._stream()
+        if self.cfg.attention == "clip":
+            fl = 2.5 * 4.0 * B * d * N * N * T * (T + 1) / 2.0       # ALGORITHMIC: 5 products against the forward's 2 (the two-kernel
+                                                                     # backward recomputes S and dP: 7 are executed)
+            self._timed("attn_clip_bwd", fl, "vlg_attention_clip_bwd", ptr(self.qkv[l]), ptr(batch["valid"]) if self.padded_slots else 0,
+                        ptr(self.att[l]), ptr(self.dh), ptr(self.lse[l]), ptr(self.delta), ptr(self.dqkv), B, T, N, d, s,
+                        nbytes=28.0 * M * d)
+            return
+        self._timed("attn_bwd", 0.0, "vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s,
+                    nbytes=7.0 * self.qkv.element_size() * M * d)
+
     def _ln_fwd(self, x, gname, y, stat, M):
         d = self.cfg.d
         self._timed("ln_fwd", 0.0, "vlg_layernorm_fwd_bf16" if y.dtype == torch.bfloat16 else "vlg_layernorm_fwd", ptr(x), ptr(self.p(gname)),
@@ -378,8 +409,7 @@ class LayoutEngine:
             x = self.x[l]
             self._ln_fwd(x, pre + "ln1_g", self.h1[l], self.stats[2 * l], M)
             self._linear(self.h1[l], self.pw(pre + "qkv_w"), self.p(pre + "qkv_b"), self.qkv[l], M, 3 * d, d, EPI_BIAS)
-            self._timed("attn_fwd", 0.0, "vlg_attention_fwd" + self._sfx, ptr(self.qkv[l]), ptr(self.att[l]), B * N, T, d, s,
-                        nbytes=4.0 * self.qkv.element_size() * M * d)
+            self._attn_fwd(l, batch, B, T, N, M)
             self._linear(self.att[l], self.pw(pre + "proj_w"), self.p(pre + "proj_b"), self.xmid[l], M, d, d,
                          EPI_BIAS | EPI_RESID, aux_in=x)
             self._ln_fwd(self.xmid[l], pre + "ln2_g", self.h2[l], self.stats[2 * l + 1], M)
@@ -470,8 +500,7 @@ class LayoutEngine:
                 self._dgrad_wgrad(self.du, self.pw(pre + "ff1_w"), self.dh, self.h2[l], pre + "ff1_w", M, ff, d)
                 self._ln_bwd(self.dh, self.xmid[l], self.stats[2 * l + 1], pre + "ln2_g", self.dx, self.dx, M)
                 self._dgrad_wgrad(self.dx, self.pw(pre + "proj_w"), self.dh, self.att[l], pre + "proj_w", M, d, d)
-                self._timed("attn_bwd", 0.0, "vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s,
-                            nbytes=7.0 * self.qkv.element_size() * M * d)
+                self._attn_bwd(l, batch, B, T, N, M)
                 self._dgrad_wgrad(self.dqkv, self.pw(pre + "qkv_w"), self.dh, self.h1[l], pre + "qkv_w", M, 3 * d, d)
                 self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)
                 self._join_reduces()
@@ -493,8 +522,7 @@ class LayoutEngine:
             on_side(("dx",), lambda: self._wgrad(self.dx, self.att[l], pre + "proj_w", M, d, d))
             self._dgrad(self.dx, self.pw(pre + "proj_w"), self.dh, M, d, d)
             before_write("dqkv")
-            self._timed("attn_bwd", 0.0, "vlg_attention_bwd" + self._sfx, ptr(self.qkv[l]), ptr(self.dh), ptr(self.dqkv), B * N, T, d, s,
-                        nbytes=7.0 * self.qkv.element_size() * M * d)
+            self._attn_bwd(l, batch, B, T, N, M)
             on_side(("dqkv",), lambda: self._wgrad(self.dqkv, self.h1[l], pre + "qkv_w", M, 3 * d, d))
             self._dgrad(self.dqkv, self.pw(pre + "qkv_w"), self.dh, M, 3 * d, d)
             before_write("dx")

@@ -44,6 +44,8 @@ SIGNATURES = {
     "vlg_attention_bwd": (I, [P, P, P, L, I, I, P]),
     "vlg_attention_fwd_bf16": (I, [P, P, L, I, I, P]),
     "vlg_attention_bwd_bf16": (I, [P, P, P, L, I, I, P]),
+    "vlg_attention_clip_fwd": (I, [P, P, P, P, L, I, I, I, P]),
+    "vlg_attention_clip_bwd": (I, [P, P, P, P, P, P, P, L, I, I, I, P]),
     "vlg_layout_loss_scratch": (I, []),
     "vlg_layout_loss": (I, [P, I, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, P]),
     "vlg_reduce_slabs": (I, [P, L, I, P, L, P]),

@@ -52,6 +52,9 @@ class LayoutConfig:
     d: int = 256                # token width
     n_layers: int = 4
     n_classes: int = N_CLASSES
+    # "slot": causal attention along T independently per (clip, slot) - the default the headline is quoted on;
+    # "clip": block-causal attention over all T*N tokens of a clip (token (t, n) sees every slot of frames <= t)
+    attention: str = "slot"
 
     @property
     def n_heads(self) -> int:
@@ -82,11 +85,16 @@ class LayoutConfig:
             raise ValueError("T must be one of 4, 8, 16, 32 (temporal tile held by one wavefront)")
         if self.N < 1 or self.B < 1 or self.n_layers < 1:
             raise ValueError("B, N, n_layers must be >= 1")
+        if self.attention not in ("slot", "clip"):
+            raise ValueError("attention must be 'slot' or 'clip'")
+        if self.attention == "clip" and (self.T * self.N) % 32 != 0:
+            raise ValueError("attention='clip' needs T*N to be a multiple of 32 (32-token MFMA tiles)")
 
     def describe(self) -> Dict[str, object]:
         return {"B": self.B, "T": self.T, "N": self.N, "d": self.d, "layers": self.n_layers,
                 "heads": self.n_heads, "d_ff": self.d_ff, "classes": self.n_classes,
-                "attention": "causal-temporal-per-slot", "box": "cxcywh-sigmoid",
+                "attention": ("causal-temporal-per-slot" if self.attention == "slot"
+                              else "block-causal-per-clip (every slot of frames <= t)"), "box": "cxcywh-sigmoid",
                 "loss": "40*smoothL1(beta=%g)+20*(1-IoU)+10*CE" % SMOOTH_L1_BETA}
 
 
@@ -141,6 +149,9 @@ def step_flops(cfg: LayoutConfig) -> Dict[str, float]:
     M, d = cfg.tokens, cfg.d
     per_layer_fwd = 24.0 * M * d * d            # QKV 6 + proj 2 + FFN 16  (x M d^2)
     attn_fwd = 4.0 * cfg.B * cfg.N * cfg.T * cfg.T * d / 2.0   # causal half
+    if cfg.attention == "clip":                                # allowed (query, key) pairs per clip: N^2 T (T + 1) / 2
+        attn_fwd = 4.0 * cfg.B * d * cfg.N * cfg.N * cfg.T * (cfg.T + 1) / 2.0
     head_fwd = 2.0 * M * d * cfg.n_out
     fwd = cfg.n_layers * (per_layer_fwd + attn_fwd) + head_fwd
-    return {"gemm_fwd_per_layer": per_layer_fwd, "fwd": fwd, "fwd_bwd": 3.0 * fwd}
+    # backward = 2 x forward for the projections; attention backward = 2.5 x its forward (5 products against 2)
+    return {"gemm_fwd_per_layer": per_layer_fwd, "fwd": fwd, "fwd_bwd": 3.0 * fwd + 0.5 * cfg.n_layers * attn_fwd}
