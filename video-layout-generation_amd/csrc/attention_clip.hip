@@ -20,7 +20,12 @@
 //                     dQ  (query owner)   S^T, dP^T = V . dO^T, dS^T = P (dP - delta) / 8, dQ += dS . K        96 MFMAs / tile
 //                     dKV (key owner)     S, dP = dO . V^T, dV += P^T . dO, dK += dS^T . Q                      128 MFMAs / tile
 //                 P is recomputed from the saved log-sum-exp (one float per query and head); delta = <dO, O> per query.
-// Algorithmic work per (clip, head): N^2 T (T + 1) / 2 visible (query, key) pairs x 4 * 64 flop forward, x 3.5 that backward.
+// Algorithmic work per (clip, head): N^2 T (T + 1) / 2 visible (query, key) pairs x 4 * 64 flop forward, x 2.5 that backward
+// (5 products; the two-kernel backward executes 7).  Measured at (32, 16, 64), d = 256 (tools/clip_attn_bench.py): forward 210 us =
+// 87 TFLOP/s = 0.55 of the fp32 MFMA peak, backward 647 us = 71 TFLOP/s algorithmic (0.45; 0.63 counting the executed products).
+// Dealing the longest blocks first took the forward from 314 to 210 us and the backward from 1 076 to 647 us (a 32-tile block
+// dealt last runs alone for 80 us).  A lazily updated reference maximum (rescale O only when the maximum moves by > 2^6) was
+// measured: 213 us - the rescale is not what the matrix pipe waits for; not kept.
 #include "common.h"
 #include "gemm_tile.h"
 
