@@ -89,3 +89,26 @@ def test_two_processes_bf16_mode(dev, tmp_path):
         full = O.synthetic_batch(cfg.B, cfg.T, cfg.N, seed=60 + step)
         loss = float(eng.train_step({k: v.to(dev) for k, v in full.items()})[0])
         assert abs(got["losses"][step] - loss) <= 2e-2 * abs(loss), (got["losses"], loss)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment (the driver's N > 1 command, as the reference's launcher is one
+    command: src/main.py:183-185): the parent starts the two ranks itself, relays ONE JSON line and returns their status.  Both
+    ranks share the one MI355X of the test box (VLG_BENCH_ONE_DEVICE=1, gloo: RCCL refuses two ranks on one device) - what is
+    checked is the launch path and the communication evidence on the line, not a transport."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VLG_BENCH_ONE_DEVICE="1", VLG_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--settle", "0",
+                        "--B", "4", "--T", "8", "--N", "16", "--d", "64", "--layers", "2", "--no-cpu-baseline", "--no-extras"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
+    c = d["comm"]
+    assert c["world"] == 2 and c["backend"] == "gloo" and [x["rank"] for x in c["ranks"]] == [0, 1]
+    assert c["buckets"] == 4 and c["bytes_allreduced_per_step"] > 0 and "exposed_comm_ms" in c
+    assert d["value"] > 0 and d["ms_per_step"] > 0

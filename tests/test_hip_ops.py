@@ -35,7 +35,8 @@ def reduce_slabs(H, slabs, stride, n, length, dev):
 
 # ------------------------------------------------------------------------ per-clip attention (option attention = "clip")
 @pytest.mark.parametrize("B,T,N,d,masked", [(2, 4, 8, 64, False), (2, 4, 8, 64, True), (3, 8, 16, 128, True), (2, 16, 24, 64, True),
-                                              (1, 16, 64, 256, False), (2, 32, 5, 64, True), (1, 4, 40, 64, False)])
+                                              (1, 16, 64, 256, False), (2, 32, 5, 64, True), (1, 4, 40, 64, False),
+                                              (1, 32, 64, 128, True)])       # BASELINE configs[3] clip: 2 048 tokens, 16 query blocks
 def test_clip_attention_fwd_bwd(H, dev, B, T, N, d, masked):
     """vlg_attention_clip_fwd / _bwd (block-causal attention over all T*N tokens of a clip, fp32 MFMA, flash-style) against the
     CPU specification oracle.layout_spec.clip_attention and its autograd (SELF-ORACLE): tiles that straddle frames (N = 5, 24,
