@@ -150,7 +150,8 @@ def self_launch(n: int) -> "int":
     made no HIP call (importing torch does not initialise the device), relay rank 0's JSON line, return the children's status.
     Never an exec: a process is started, not replaced."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           "--", os.path.abspath(__file__)] + sys.argv[1:]      # "--": the launcher's argparse would otherwise prefix-match OUR flags (--d ...)
     env = dict(os.environ, VLG_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
