@@ -53,12 +53,13 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 DOMINANT = "gemm_wgrad"          # largest share of device time (profiles/r0*_kernel_stats.csv)
-GEMM_FAMILIES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_head")
+GEMM_FAMILIES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_head", "gemm_pair")
 KERNEL_OF_FAMILY = {             # rocprofv3 kernel names (profiles/) for each timed family
     "gemm_fwd": "gemm_f32_kernel<128,128,32|16,true,true,*,false,false>",
     "gemm_dgrad": "gemm_f32_kernel<128,128,32|16,true,false,*,false,false>",
     "gemm_wgrad": "gemm_f32_kernel<128,128,32,false,false,0,true,false>",
     "gemm_head": "gemm_f32_kernel<128,32,32,..>/<32,128,32,..>",
+    "gemm_pair": "gemm_pair_kernel<64,*> (data gradient + weight gradient of a projection in one launch: few tokens per GPU)",
     "embed_fwd": "embed_fwd_kernel", "embed_bwd": "embed_bwd_kernel", "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel",
     "attn_fwd": "attn16_fwd_kernel", "attn_bwd": "attn16_bwd_kernel", "loss": "layout_loss_kernel", "adam": "adam_kernel",
 }
@@ -426,7 +427,8 @@ def main():
     # Inside the timed region only the dominant kernel (the weight-gradient GEMM instantiation: top of
     # every rocprof summary in profiles/) is bracketed with events, and only on every 4th step (16 launches each):
     # an event pair around each of its launches costs ~2 % of `value`, around all ~70 GEMM launches far more.
-    ktimer = None if (args.no_kernel_timing or args.graph) else KernelTimer(only=(DOMINANT,))   # events are not part of a replayed graph
+    # (few tokens per GPU - non-default --B: the backward pairs a projection's data and weight gradient in one launch, family "gemm_pair")
+    ktimer = None if (args.no_kernel_timing or args.graph) else KernelTimer(only=(DOMINANT, "gemm_pair"))   # events are not part of a replayed graph
     sampled_steps = 0
     sync_all()
     t0 = time.perf_counter()
@@ -499,7 +501,9 @@ def main():
         line["comm"] = comm
         roof, roof_hbm = None, None
         if eng.timer is not None:
-            s = eng.timer.summary()[DOMINANT]
+            summ = eng.timer.summary()
+            dom = DOMINANT if DOMINANT in summ else "gemm_pair"
+            s = summ[dom]
             # untimed diagnostic pass: EVERY launch bracketed (rank 0 only, so WITHOUT the reducer: a collective here
             # would have no partner on the other ranks)
             eng.timer = KernelTimer()
@@ -509,7 +513,7 @@ def main():
             allf = eng.timer.summary()
             eng.timer = None
             achieved = s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
-            traffic = committed_traffic(DOMINANT) if args.dtype == "f32" else None
+            traffic = committed_traffic(dom) if args.dtype == "f32" else None
             bound, peak, unit = "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
             names = KERNEL_OF_FAMILY
             if args.dtype == "f32x3":
@@ -526,7 +530,7 @@ def main():
             roof = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(s["bytes_per_launch"]),
-                    "kernel": names[DOMINANT], "launches": s["launches"], "launches_per_step": launches_per_step,
+                    "kernel": names[dom], "launches": s["launches"], "launches_per_step": launches_per_step,
                     "avg_launch_us": round(1e3 * s["avg_ms"], 2),
                     "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
                     "share_of_step": round(launches_per_step * s["avg_ms"] / ms_per_step, 4),
