@@ -21,11 +21,14 @@
 //                     dKV (key owner)     S, dP = dO . V^T, dV += P^T . dO, dK += dS^T . Q                      128 MFMAs / tile
 //                 P is recomputed from the saved log-sum-exp (one float per query and head); delta = <dO, O> per query.
 // Algorithmic work per (clip, head): N^2 T (T + 1) / 2 visible (query, key) pairs x 4 * 64 flop forward, x 2.5 that backward
-// (5 products; the two-kernel backward executes 7).  Measured at (32, 16, 64), d = 256 (tools/clip_attn_bench.py): forward 210 us =
-// 87 TFLOP/s = 0.55 of the fp32 MFMA peak, backward 647 us = 71 TFLOP/s algorithmic (0.45; 0.63 counting the executed products).
+// (5 products; the two-kernel backward executes 7).  Measured at (32, 16, 64), d = 256 (tools/clip_attn_bench.py, box to box
+// +-4 %): forward 195-204 us = 90-94 TFLOP/s = 0.57-0.59 of the fp32 MFMA peak, backward 600-620 us = 74-76 TFLOP/s algorithmic
+// (0.47-0.48; 0.66 counting the executed products); (8, 32, 64), d = 512: 0.63 / 0.52.
 // Dealing the longest blocks first took the forward from 314 to 210 us and the backward from 1 076 to 647 us (a 32-tile block
-// dealt last runs alone for 80 us).  A lazily updated reference maximum (rescale O only when the maximum moves by > 2^6) was
-// measured: 213 us - the rescale is not what the matrix pipe waits for; not kept.
+// dealt last runs alone for 80 us); occupancy did the rest: the key-owner kernel held to 256 registers (two waves per SIMD
+// instead of one: 647 -> 599 us), the forward to 168 (three waves per SIMD, 8 registers spilled: 210 -> 195 us).  A lazily
+// updated reference maximum (rescale O only when the maximum moves by > 2^6) was measured: 213 us - the rescale is not what
+// the matrix pipe waits for; not kept.
 #include "common.h"
 #include "gemm_tile.h"
 
@@ -92,6 +95,23 @@ __device__ __forceinline__ f32x16 dot64(const float (&a)[32], const float (&b)[3
     for (int i = 0; i < 32; ++i) c = MFMA32(a[i], b[i], c);
     return c;
 }
+// the same with the A fragment read from the row-major LDS tile as it is consumed (four values per ds_read_b128: the
+// fragment never occupies 32 registers at once)
+__device__ __forceinline__ f32x16 dot64_rows(const float* Xs, int l31, int h, const float (&b)[32]) {
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    const float* p = Xs + l31 * CLDR + 32 * h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 t = ld4(p + 4 * q);
+        c = MFMA32(t.x, b[4 * q], c);
+        c = MFMA32(t.y, b[4 * q + 1], c);
+        c = MFMA32(t.z, b[4 * q + 2], c);
+        c = MFMA32(t.w, b[4 * q + 3], c);
+    }
+    return c;
+}
 // acc[dt] (rows = the A operand's rows, cols = dims 32 dt + l31) += sum over the tile's 32 tokens of a[token] Xt[dim][token]
 __device__ __forceinline__ void contract32(f32x16 (&acc)[2], const float (&a)[16], const float* Xt, int l31, int h) {
 #pragma unroll
@@ -122,7 +142,7 @@ __device__ __forceinline__ void store_rows(float* __restrict__ dst, int64_t ld, 
 #define CLIP_SCALE 0.125f
 
 // ---------------------------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(256) void attn_clip_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ valid,
+__global__ __launch_bounds__(256, 3) void attn_clip_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ valid,
                                                             float* __restrict__ out, float* __restrict__ lse, int T, int N, int d) {
     __shared__ __attribute__((aligned(16))) float Ks[CKT * CLDR];
     __shared__ __attribute__((aligned(16))) float Vt[CHD * CLDT];
@@ -180,9 +200,7 @@ __global__ __launch_bounds__(256) void attn_clip_fwd_kernel(const float* __restr
         if (j + 1 < ntiles) tile_load(j + 1, kn, vn, frn);           // in flight under this tile's MFMAs
         const int k0 = j * CKT;
         if (!wact || k0 / N > tq_max) continue;                      // every key of the tile lies in a later frame
-        float kf[32];
-        frag_rows(kf, Ks, l31, h);
-        f32x16 st = dot64(kf, qf);                                   // S^T[key (r, h)][query l31], log2 domain
+        f32x16 st = dot64_rows(Ks, l31, h, qf);                      // S^T[key (r, h)][query l31], log2 domain
         if (valid != nullptr || (k0 + CKT - 1) / N > tq_min) {
             int fr[16];
             rows16i(fr, kfr, h);
@@ -302,9 +320,7 @@ __global__ __launch_bounds__(256) void attn_clip_dq_kernel(const float* __restri
         if (!wact || k0 / N > tq_max) continue;
         float ds[16];
         {
-            float kf[32];
-            frag_rows(kf, Ks, l31, h);
-            const f32x16 st = dot64(kf, qf);                         // S^T, log2 domain
+            const f32x16 st = dot64_rows(Ks, l31, h, qf);            // S^T, log2 domain
 #pragma unroll
             for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(st[r] - lse_q);      // P^T
         }
@@ -318,9 +334,7 @@ __global__ __launch_bounds__(256) void attn_clip_dq_kernel(const float* __restri
             }
         }
         {
-            float vf[32];
-            frag_rows(vf, Vs, l31, h);
-            const f32x16 dpt = dot64(vf, dof);                       // dP^T[key][query] = <V[key], dO[query]>
+            const f32x16 dpt = dot64_rows(Vs, l31, h, dof);          // dP^T[key][query] = <V[key], dO[query]>
 #pragma unroll
             for (int r = 0; r < 16; ++r) ds[r] = ds[r] * (dpt[r] - del_q) * CLIP_SCALE;       // dS^T
         }
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_clip_dq_kernel(const float* __restri
 }
 
 // --------------------------------------------------------------------------------------- backward, key owner (dK, dV)
-__global__ __launch_bounds__(256) void attn_clip_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ valid,
+__global__ __launch_bounds__(256, 2) void attn_clip_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ valid,
                                                             const float* __restrict__ dout, const float* __restrict__ lse,
                                                             const float* __restrict__ delta, float* __restrict__ dqkv,
                                                             int T, int N, int d) {
@@ -402,9 +416,7 @@ __global__ __launch_bounds__(256) void attn_clip_dkv_kernel(const float* __restr
         if (!wact || (q0 + CKT - 1) / N < tk_min) continue;          // every query of the tile lies in an earlier frame
         float p[16], ds[16];
         {
-            float qfm[32];
-            frag_rows(qfm, Qs, l31, h);
-            const f32x16 s = dot64(qfm, kf);                         // S[query (r, h)][key l31], log2 domain
+            const f32x16 s = dot64_rows(Qs, l31, h, kf);             // S[query (r, h)][key l31], log2 domain
             float ls[16];
             rows16(ls, qlse, h);
             int fr[16];
@@ -417,9 +429,7 @@ __global__ __launch_bounds__(256) void attn_clip_dkv_kernel(const float* __restr
             }
         }
         {
-            float gfm[32];
-            frag_rows(gfm, Gs, l31, h);
-            const f32x16 dp = dot64(gfm, vf);                        // dP[query][key] = <dO[query], V[key]>
+            const f32x16 dp = dot64_rows(Gs, l31, h, vf);            // dP[query][key] = <dO[query], V[key]>
             float dl[16];
             rows16(dl, qdel, h);
 #pragma unroll
