@@ -742,14 +742,16 @@ static bool gemm_small_tiles() {
     }
     return on == 1;
 }
-// Measured (tools/shard_bench.py, one box): 64x64 tiles pay up to ~1 024 blocks of 128x128 - four resident blocks per CU
-// overlap one block's prologue / epilogue with the others' MFMAs - B = 4: 1.75 -> 1.12 ms, B = 8: 1.87 -> 1.76, B = 16: 3.12 -> 3.01,
-// B = 32 (the d x d products): 5.59 -> 5.55.
+// Measured (tools/shard_bench.py, interleaved repeated runs on one box): 64x64 tiles pay while the 128x128 tiles would not fill
+// the 512 block slots of the chip (2 per CU) - four resident 64x64 blocks overlap one block's prologue / epilogue with the
+// others' MFMAs: B = 4: 1.75 -> 1.05 ms, B = 8: 1.79 -> 1.76, B = 16: 3.11 -> 3.05.  A launch of exactly 512 blocks (the d x d
+// products of the headline step) is FASTER on 128x128 tiles (their higher arithmetic intensity: K = 4096 asymptote 150 vs 140
+// TFLOP/s; the step 5.55 vs 5.63 ms with a threshold of 1 025 - a first single-run sweep had suggested the opposite).
 static int gemm_small_below() {                  // VLG_GEMM_SMALL_BELOW (read once): 128x128 block count under which 64x64 tiles are taken
     static int thr = -1;
     if (thr < 0) {
         const char* e = getenv("VLG_GEMM_SMALL_BELOW");
-        thr = e ? atoi(e) : 1025;
+        thr = e ? atoi(e) : 512;
     }
     return thr;
 }
