@@ -10,8 +10,9 @@ batch of synthetic clips already resident in HBM.  Workload at every N: (B,T,N_s
 d=256 per GPU (weak scaling: per-GPU clips fixed, global batch = 32 * N).  One JSON line on rank 0.
 
 Objects on the line besides the contract's fields:
-  roofline        the dominant kernel (largest summed device time of the step: the weight-gradient GEMM): algorithmic
-                  FLOP per launch / its average launch duration, from HIP events recorded on the launch stream INSIDE
+  roofline        the dominant kernel (largest summed device time of the step: gemm_pair_kernel - since round 3 a projection's
+                  weight gradient and data gradient run as ONE launch; with VLG_GEMM_PAIR=0 | 1 the weight-gradient GEMM alone):
+                  algorithmic FLOP per launch / its average launch duration, from HIP events recorded on the launch stream INSIDE
                   the timed steps (every 4th step), vs the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
                   `share_of_step` = launches per step x that duration / ms_per_step; `traffic` = HBM bytes per launch from
                   the committed PMC pass (profiles/pmc_traffic.json) IF that file was taken from these kernel sources
@@ -52,14 +53,15 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
-DOMINANT = "gemm_wgrad"          # largest share of device time (profiles/r0*_kernel_stats.csv)
+DOMINANT = "gemm_wgrad"          # largest share of device time (profiles/r0*_kernel_stats.csv); since round 3 the weight gradients run
+                                 # paired with their data gradients (family "gemm_pair", 46 % of device time): the fallback below
 GEMM_FAMILIES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_head", "gemm_pair")
 KERNEL_OF_FAMILY = {             # rocprofv3 kernel names (profiles/) for each timed family
     "gemm_fwd": "gemm_f32_kernel<128,128,32|16,true,true,*,false,false>",
     "gemm_dgrad": "gemm_f32_kernel<128,128,32|16,true,false,*,false,false>",
     "gemm_wgrad": "gemm_f32_kernel<128,128,32,false,false,0,true,false>",
     "gemm_head": "gemm_f32_kernel<128,32,32,..>/<32,128,32,..>",
-    "gemm_pair": "gemm_pair_kernel<64,*> (data gradient + weight gradient of a projection in one launch: few tokens per GPU)",
+    "gemm_pair": "gemm_pair_kernel<128|64, epilogue> (data gradient + weight gradient of one projection in ONE launch)",
     "embed_fwd": "embed_fwd_kernel", "embed_bwd": "embed_bwd_kernel", "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel",
     "attn_fwd": "attn16_fwd_kernel", "attn_bwd": "attn16_bwd_kernel", "loss": "layout_loss_kernel", "adam": "adam_kernel",
 }
@@ -427,7 +429,7 @@ def main():
     # Inside the timed region only the dominant kernel (the weight-gradient GEMM instantiation: top of
     # every rocprof summary in profiles/) is bracketed with events, and only on every 4th step (16 launches each):
     # an event pair around each of its launches costs ~2 % of `value`, around all ~70 GEMM launches far more.
-    # (few tokens per GPU - non-default --B: the backward pairs a projection's data and weight gradient in one launch, family "gemm_pair")
+    # (the backward pairs a projection's data and weight gradient in one launch, family "gemm_pair"; VLG_GEMM_PAIR=0 | 1 separates them)
     ktimer = None if (args.no_kernel_timing or args.graph) else KernelTimer(only=(DOMINANT, "gemm_pair"))   # events are not part of a replayed graph
     sampled_steps = 0
     sync_all()

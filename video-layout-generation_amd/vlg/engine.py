@@ -536,9 +536,10 @@ class LayoutEngine:
         self._backward_tail(batch, B, T, N, M, reducer)
 
     def _pair_shapes(self, M: int) -> bool:
-        """the paired backward is taken where the library fuses the launches (few tokens); elsewhere the separate calls keep
-        the per-kernel timing families of bench.py meaningful (VLG_GEMM_PAIR=2 pairs every shape)"""
-        mode = int(os.environ.get("VLG_GEMM_PAIR", "1"))
+        """the paired backward (one C-ABI call per projection; the library fuses the two launches where its VLG_GEMM_PAIR mode
+        says so: 2 = every shape, the default; 1 = few tokens only - then larger batches keep the separate calls and with
+        them bench.py's per-kernel timing families; 0 = never)"""
+        mode = int(os.environ.get("VLG_GEMM_PAIR", "2"))
         return mode >= 2 or (mode == 1 and M <= 16384)
 
     def _backward_tail(self, batch, B, T, N, M, reducer) -> None:
