@@ -286,6 +286,36 @@ def test_linear_dgrad_wgrad_is_the_two_calls(H, dev, M, N, K, mul):
     assert_close(g[N * K:], dy.double().sum(0).float(), rtol=1e-4, atol=1e-3, what="paired bias gradient")
 
 
+@pytest.mark.parametrize("M,N,K,mul,dy16", [(4096, 256, 1024, True, False), (4096, 1024, 256, False, True), (2048, 256, 256, False, False),
+                                            (32768, 768, 256, False, True)])
+def test_linear_dgrad_wgrad_bf16_storage_is_the_two_calls(H, dev, M, N, K, mul, dy16):
+    """The bf16-storage step's pairs (bf16 W / X / dX, dY bf16 or fp32; csrc/gemm_bf16.hip:gemm16_pair_kernel): one launch,
+    bit for bit the two launches."""
+    lib = H.load()
+    torch.manual_seed(M + N + K)
+    bf = torch.bfloat16
+    dy = torch.randn(M, N).to(bf if dy16 else torch.float32).to(dev)
+    w, x = (torch.randn(N, K) / math.sqrt(K)).to(bf).to(dev), torch.randn(M, K).to(bf).to(dev)
+    aux = torch.randn(M, K).to(bf).to(dev) if mul else None
+    FL = H.EPI_BF16 | (H.EPI_A_BF16 if dy16 else 0) | H.EPI_B_BF16
+    epi = H.EPI_MUL if mul else H.EPI_NONE
+    ns = lib.vlg_linear_wgrad_slabs_for(M, N, K, H.EPI_BF16)
+    L = N * K + N
+    out = []
+    for fused in (False, True):
+        slabs = torch.full((ns * L,), float("nan"), device=dev)
+        dx = torch.full((M, K), float("nan"), device=dev, dtype=bf)
+        if fused:
+            H.call("vlg_linear_dgrad_wgrad", dy.data_ptr(), N, w.data_ptr(), K, dx.data_ptr(), K, H.ptr(aux), x.data_ptr(), K,
+                   slabs.data_ptr(), L, slabs.numel(), M, N, K, epi | FL | H.EPI_OUT_BF16, stream())
+        else:
+            H.call("vlg_linear_wgrad", dy.data_ptr(), N, x.data_ptr(), K, slabs.data_ptr(), L, slabs.numel(), M, N, K, FL, stream())
+            H.call("vlg_linear_dgrad", dy.data_ptr(), N, w.data_ptr(), K, dx.data_ptr(), K, H.ptr(aux), M, N, K, epi | FL | H.EPI_OUT_BF16, stream())
+        out.append((dx, reduce_slabs(H, slabs, L, ns, L, dev)))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert bool(torch.isfinite(out[1][0].float()).all()) and bool(torch.isfinite(out[1][1]).all())
+
+
 def test_linear_chained_tiles(H, dev):
     """Multi-round launches: a block computes a run of N tiles back to back (the K loop continues into the next tile).
     1024 tiles here -> runs of two; forward with bias, forward with GELU + saved derivative, data gradient with the

@@ -812,6 +812,7 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
 int vlg_gemm16_fwd(GemmArgs g, int epilogue, int io, hipStream_t s);
 int vlg_gemm16_dgrad(GemmArgs g, int epilogue, int io, hipStream_t s);
 int vlg_gemm16_wgrad(GemmArgs g, int io, hipStream_t s);
+int vlg_gemm16_pair(GemmArgs gd, GemmArgs gw, int epilogue, bool dy_bf16, hipStream_t s);
 // fp32 operands split into three bf16 terms, six bf16 MFMAs per product block (gemm_split.hip)
 int vlg_gemm_split_fwd(GemmArgs g, int epilogue, hipStream_t s);
 int vlg_gemm_split_dgrad(GemmArgs g, int epilogue, hipStream_t s);
@@ -1003,6 +1004,27 @@ extern "C" int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, in
                                       int64_t M, int N, int K, int epilogue, void* stream) {
     // dX[M,K] = dY[M,N] . W[N,K] (x aux_in with VLG_EPI_MUL)   and   slab[s] = dY^T . X, column sums of dY  - the results of
     // vlg_linear_wgrad followed by vlg_linear_dgrad with the same arguments, bit for bit
+    // the bf16-storage step (bf16 W / X / dX, dY bf16 or fp32): one launch of the bf16-tile kernels at every shape
+    const int st_bits = epilogue & (VLG_EPI_A_BF16 | VLG_EPI_B_BF16 | VLG_EPI_OUT_BF16);
+    if ((epilogue & VLG_EPI_BF16) && (st_bits & ~VLG_EPI_A_BF16) == (VLG_EPI_B_BF16 | VLG_EPI_OUT_BF16) && gemm_pair_mode() > 1 && N > 32 && K > 32) {
+        const int epi = epilogue & ~(VLG_EPI_BF16 | VLG_EPI_A_BF16 | VLG_EPI_B_BF16 | VLG_EPI_OUT_BF16);
+        if (epi != VLG_EPI_NONE && epi != VLG_EPI_MUL) return VLG_ERR_SHAPE;
+        if (M < 1 || (N & 7) || (K & 7) || ldy < N || ldw < K || ldx < K || ldxx < K) return VLG_ERR_SHAPE;
+        const bool a16 = (st_bits & VLG_EPI_A_BF16) != 0;
+        if (!vlg_aligned16(dY) || !vlg_aligned16(W) || !vlg_aligned16(X) || !dX || !slabs || (a16 && (ldy & 7)) || (ldw & 7) || (ldxx & 7) || (ldx & 7))
+            return VLG_ERR_ALIGN;
+        if (epi == VLG_EPI_MUL && !aux_in) return VLG_ERR_SHAPE;
+        GemmArgs gd{}, gw{};
+        gd.A = dY; gd.B = W; gd.C = dX; gd.aux_in = aux_in;
+        gd.M = M; gd.N = K; gd.Kc = N; gd.lda = ldy; gd.ldb = ldw; gd.ldc = ldx;
+        gd.splits = 1; gd.kc_per_split = N;
+        gw.A = dY; gw.B = X; gw.C = slabs;
+        gw.M = N; gw.N = K; gw.Kc = M; gw.lda = ldy; gw.ldb = ldxx; gw.ldc = K;
+        wgrad_plan(M, N, K, &gw.splits, &gw.kc_per_split, true);
+        if (slab_stride < (int64_t)N * K + N || slab_capacity < (int64_t)gw.splits * slab_stride) return VLG_ERR_SHAPE;
+        gw.slab_stride = slab_stride; gw.colsum_off = (int64_t)N * K;
+        return vlg_gemm16_pair(gd, gw, epi, a16, (hipStream_t)stream);
+    }
     const bool native = (epilogue & ~VLG_EPI_MUL) == 0;
     bool small_w = false;
     int splits = 1; int64_t per = 0;
@@ -1010,9 +1032,8 @@ extern "C" int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, in
     const bool small_d = gemm_wants_small(M, K, 1);
     const bool pair = native && gemm_pair_mode() > 0 && small_w == small_d && (small_d || gemm_pair_mode() > 1) && N > 32 && K > 32;
     if (!pair) {
+        // (bf16 storage: A = the shared dY, B = W of the data gradient AND X of the weight gradient, OUT = dX)
         const int wflags = epilogue & (VLG_EPI_BF16 | VLG_EPI_SPLIT3 | VLG_EPI_A_BF16 | VLG_EPI_B_BF16);
-        // (storage bits of the pair's three activation operands differ per call: callers with bf16 storage use the two entry points)
-        if (epilogue & (VLG_EPI_A_BF16 | VLG_EPI_B_BF16 | VLG_EPI_OUT_BF16)) return VLG_ERR_SHAPE;
         const int rc = vlg_linear_wgrad(dY, ldy, X, ldxx, slabs, slab_stride, slab_capacity, M, N, K, wflags, stream);
         if (rc != 0) return rc;
         return vlg_linear_dgrad(dY, ldy, W, ldw, dX, ldx, aux_in, M, N, K, epilogue, stream);

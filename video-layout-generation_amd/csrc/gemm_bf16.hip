@@ -22,8 +22,14 @@
 #include "gemm_tile16.h"
 #include <stdlib.h>
 
+// LDS elements (bf16) of one block: both operand tiles, double-buffered
+template <int BM, int BN, int BK16, bool A_KC, bool B_KC>
+constexpr int gemm16_smem_elems() { return 2 * (Tile16<BM, A_KC, BK16>::ELEMS + Tile16<BN, B_KC, BK16>::ELEMS); }
+
+// the kernel body as a function of (arguments, LDS, block number, block count): one problem per launch (gemm_bf16_kernel) or
+// a projection's data gradient and weight gradient side by side (gemm16_pair_kernel), as in gemm.hip
 template <int BM, int BN, int BK16, bool A_KC, bool B_KC, int EPI, bool COLSUM, typename EA, typename EB, typename EO>
-__device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
+__device__ __forceinline__ void gemm16_body(const GemmArgs& g, bf16_t* const smem, const int bid, const int nwg) {
     constexpr int DEPTH = BK16 == 64 ? 2 : 1;          // register-resident tiles in flight besides the two LDS buffers
     // (a 32-deep, DEPTH 1, 4-blocks-per-CU instantiation was measured: +4 % on forward / data gradient, -30 % on the
     // weight gradient whose column-sum registers then spill - not kept)
@@ -38,11 +44,9 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     using TA = Tile16<BM, A_KC, BK16>;
     using TB = Tile16<BN, B_KC, BK16>;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (TA::ELEMS + TB::ELEMS)];
     bf16_t* const As0 = smem;
     bf16_t* const Bs0 = smem + 2 * TA::ELEMS;
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     const int ntile = g.tiles_m * g.tiles_n;
@@ -221,7 +225,41 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
     using EA = std::conditional_t<(IO & 1) != 0, bf16_t, float>;
     using EB = std::conditional_t<(IO & 2) != 0, bf16_t, float>;
     using EO = std::conditional_t<(IO & 4) != 0, bf16_t, float>;
-    gemm16_body<BM, BN, 64, A_KC, B_KC, EPI, COLSUM, EA, EB, EO>(g);
+    __shared__ __attribute__((aligned(16))) bf16_t smem[gemm16_smem_elems<BM, BN, 64, A_KC, B_KC>()];
+    gemm16_body<BM, BN, 64, A_KC, B_KC, EPI, COLSUM, EA, EB, EO>(g, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// A projection's data gradient (blocks [0, nd_pad): nd real, padded to a multiple of 8 for the XCD mapping of the second
+// problem) and weight gradient (the rest) in ONE launch - csrc/gemm.hip, gemm_pair_kernel.  The bf16-storage step's
+// combinations: dY bf16 or fp32 (A16), W / X bf16, dX (+ the multiply epilogue's operand) bf16.
+template <int EPI_D, bool A16>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm16_pair_kernel(const GemmArgs gd, const GemmArgs gw, const int nd, const int nd_pad) {
+    using EA = std::conditional_t<A16, bf16_t, float>;
+    constexpr int FD = gemm16_smem_elems<128, 128, 64, true, false>(), FW = gemm16_smem_elems<128, 128, 64, false, false>();
+    __shared__ __attribute__((aligned(16))) bf16_t smem[FD > FW ? FD : FW];
+    const int b = (int)blockIdx.x;
+    if (b < nd_pad) {
+        if (b < nd) gemm16_body<128, 128, 64, true, false, EPI_D, false, EA, bf16_t, bf16_t>(gd, smem, b, nd);
+    } else {
+        gemm16_body<128, 128, 64, false, false, VLG_EPI_NONE, true, EA, bf16_t, float>(gw, smem, b - nd_pad, (int)gridDim.x - nd_pad);
+    }
+}
+template <int EPI_D, bool A16>
+static int launch16_pair(GemmArgs gd, GemmArgs gw, hipStream_t s) {
+    gd.tiles_m = (int)((gd.M + 127) / 128); gd.tiles_n = (gd.N + 127) / 128; gd.clock_probe = nullptr; gd.run = 1;
+    gw.tiles_m = (int)((gw.M + 127) / 128); gw.tiles_n = (gw.N + 127) / 128; gw.clock_probe = nullptr; gw.run = 1;
+    const int64_t nd = (int64_t)gd.tiles_m * gd.tiles_n, nw = (int64_t)gw.tiles_m * gw.tiles_n * gw.splits;
+    const int64_t nd_pad = (nd + 7) / 8 * 8;
+    if (nd < 1 || nw < 1 || nd_pad + nw > 0x7fffffff) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL((gemm16_pair_kernel<EPI_D, A16>), dim3((unsigned)(nd_pad + nw)), dim3(GEMM_THREADS), 0, s, gd, gw, (int)nd, (int)nd_pad);
+    return vlg_last_error();
+}
+// bf16-storage pair (W / X / dX bf16): dy_bf16 = the shared dY is bf16 (else fp32: a residual-stream gradient)
+int vlg_gemm16_pair(GemmArgs gd, GemmArgs gw, int epilogue, bool dy_bf16, hipStream_t s) {
+    if ((gd.ldc & 7) || !vlg_aligned16(gd.C) || (gd.Kc & 7) || (gd.N & 7) || (gw.M & 7) || (gw.N & 7) || gw.M <= 32) return VLG_ERR_SHAPE;
+    if (epilogue == VLG_EPI_NONE) return dy_bf16 ? launch16_pair<VLG_EPI_NONE, true>(gd, gw, s) : launch16_pair<VLG_EPI_NONE, false>(gd, gw, s);
+    if (epilogue == VLG_EPI_MUL) return dy_bf16 ? launch16_pair<VLG_EPI_MUL, true>(gd, gw, s) : launch16_pair<VLG_EPI_MUL, false>(gd, gw, s);
+    return VLG_ERR_SHAPE;
 }
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, int IO>
 static int launch16(GemmArgs g, hipStream_t s) {

@@ -225,8 +225,8 @@ class LayoutEngine:
         self.group_reduce = os.environ.get("VLG_GROUP_REDUCE", "1") == "1" and not self.overlap_wgrad and not self.overlap_small
         # a projection's data gradient and weight gradient through one call (one launch at few tokens): fp32 tensors, single
         # stream; the library decides per shape (VLG_GEMM_PAIR)
-        self.pair_backward = (not self.bf16_store and not self.overlap_wgrad and not self.overlap_small and not self.gelu_on_load
-                              and self.precision == "fp32" and os.environ.get("VLG_PAIR_BACKWARD", "1") == "1")
+        self.pair_backward = (not self.overlap_wgrad and not self.overlap_small and not self.gelu_on_load
+                              and self.precision in ("fp32", "bf16") and os.environ.get("VLG_PAIR_BACKWARD", "1") == "1")
         if self.group_reduce:
             pad = lambda v: (v + 3) // 4 * 4
             layer = sum(pad(v) for v in need[2:6]) + 2 * pad(need[1])
@@ -334,8 +334,11 @@ class LayoutEngine:
         arena = self._arena("w", n_slabs * stride)
         nb = (dy.element_size() * M * N * 2 + w.element_size() * N * K + dx.element_size() * M * K * (1 + (aux_in is not None)) +
               x.element_size() * M * K + 4.0 * n_slabs * stride)
+        bits = self._storage_bits(dy, w, dx)       # bf16 mode: A = the shared dY, B = W (data gradient) AND X (weight gradient), OUT = dX
+        if (x.dtype == torch.bfloat16) != (w.dtype == torch.bfloat16):
+            raise ValueError("paired backward: X and W must have the same storage type")
         self._timed("gemm_pair", 4.0 * M * N * K, "vlg_linear_dgrad_wgrad", ptr(dy), N, ptr(w), K, ptr(dx), K, ptr(aux_in),
-                    ptr(x), K, ptr(arena), stride, arena.numel(), M, N, K, epi | self.gemm_flags, self._stream(), nbytes=nb)
+                    ptr(x), K, ptr(arena), stride, arena.numel(), M, N, K, epi | self.gemm_flags | bits, self._stream(), nbytes=nb)
         self._reduce("w", stride, n_slabs, self.layout[wname][0], stride)
 
     def _attn_fwd(self, l: int, batch, B, T, N, M) -> None:
