@@ -13,15 +13,20 @@ from oracle import layout_spec as O
 pytestmark = pytest.mark.gpu
 
 
-def test_bucketed_variable_n_training(tmp_path, monkeypatch):
+@pytest.mark.parametrize("attention", ["slot", "clip"])
+def test_bucketed_variable_n_training(tmp_path, monkeypatch, attention):
+    """BASELINE configs[4] through the real Trainer; attention = "clip" (VLG_ATTENTION): the per-clip option on bucketed batches -
+    padded slots are masked as keys (the trainer builds the engine with padded_slots = variable_n)."""
     (tmp_path / "src").mkdir()
     monkeypatch.chdir(tmp_path / "src")
+    monkeypatch.setenv("VLG_ATTENTION", attention)
     from trainer import Trainer
     from vlg.spec import param_shapes
     random.seed(1024)
     args = reference_args(tmp_path / "exp", batch_size=4, epochs=1, print_freq=1, n_frames=8, n_slots=32, d_model=64,
                           n_layers=2, train_clips=64, val_clips=16, variable_n=1)
     tr = Trainer(args)
+    assert tr.cfg.attention == attention and tr.engine.padded_slots
     shapes = set()
     p = O.init_params(param_shapes(tr.cfg), seed=1024)
     checked = 0
@@ -34,7 +39,7 @@ def test_bucketed_variable_n_training(tmp_path, monkeypatch):
         batch = {k: v.cpu() for k, v in batch.items()}    # the oracle's copy
         loss = tr.engine.forward_backward(dev_batch)
         if checked < 3:                                   # oracle comparison on the first few buckets (initial weights)
-            parts, grads = O.loss_and_grads(p, batch, tr.cfg.n_layers)
+            parts, grads = O.loss_and_grads(p, batch, tr.cfg.n_layers, attention=attention)
             assert_close(loss, torch.tensor(parts), rtol=1e-4, atol=1e-6, what="loss N=%d" % n)
             for name in ("cls_emb", "l0.qkv_w", "l1.ff2_w", "head_w"):
                 g, w = tr.engine.named_grads()[name], grads[name]
