@@ -141,12 +141,15 @@ def test_eval_generate_sequence_entry(tmp_path, monkeypatch, dev):
     assert tr.eval_generate_sequence(str(tmp_path / "nope.png"), files["img2"][0], files["seg1"][0], files["seg2"][0]) is None
 
 
-def test_layout_rollout_values_and_entry(tmp_path, monkeypatch, dev):
+@pytest.mark.parametrize("attention", ["slot", "clip"])
+def test_layout_rollout_values_and_entry(tmp_path, monkeypatch, dev, attention):
     """Token mode: generate_sequence's 8 predictions vs the CPU restatement (teacher-forced on the HIP rollout's own
-    window), and eval_generate_sequence says what it cannot do instead of logging a false 'path not exists'."""
+    window), and eval_generate_sequence says what it cannot do instead of logging a false 'path not exists'.  With the
+    per-clip attention option the rollout masks padded slots (reserved class id) as keys, as training does."""
     (tmp_path / "src").mkdir()
     monkeypatch.chdir(tmp_path / "src")
     monkeypatch.delenv("VLG_MODEL", raising=False)
+    monkeypatch.setenv("VLG_ATTENTION", attention)
     from trainer import Trainer
     cfgk = dict(batch_size=3, epochs=1, print_freq=1, n_frames=8, n_slots=8, d_model=64, n_layers=2, train_clips=6, val_clips=3)
     tr = Trainer(reference_args(tmp_path / "exp", **cfgk))
@@ -159,7 +162,8 @@ def test_layout_rollout_values_and_entry(tmp_path, monkeypatch, dev):
     cls, box = cls0.clone(), box0.clone()
     with torch.no_grad():
         for i in range(steps):
-            logits, raw = O.forward(params, cls, box, tr.cfg.n_layers)
+            logits, raw = O.forward(params, cls, box, tr.cfg.n_layers, attention=attention,
+                                    valid=(cls < tr.cfg.n_classes).float())
             last = logits[:, -1]                                                   # (B,N,C)
             top2 = last.topk(2, dim=-1).values
             clear = (top2[..., 0] - top2[..., 1]) > 1e-4 * float(last.abs().max())

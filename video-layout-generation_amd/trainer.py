@@ -479,10 +479,12 @@ class Trainer:
         box = slot_box.clone().to(self.device)
         B, T, N = cls.shape
         out_c, out_b = [], []
-        dummy = {"tgt_class": torch.zeros_like(cls), "tgt_box": torch.zeros_like(box),
-                 "valid": torch.zeros((B, T, N), dtype=torch.float32, device=self.device)}
+        dummy = {"tgt_class": torch.zeros_like(cls), "tgt_box": torch.zeros_like(box)}
         for _ in range(steps):
-            self.engine.forward(dict(dummy, slot_class=cls.contiguous(), slot_box=box.contiguous()))
+            # valid: padded slots carry the reserved class id (vlg/data.py) - with attention = "clip" they must not be attended
+            # to; the loss the forward also evaluates against the dummy targets is not used
+            valid = (cls < self.cfg.n_classes).to(torch.float32).contiguous()
+            self.engine.forward(dict(dummy, slot_class=cls.contiguous(), slot_box=box.contiguous(), valid=valid))
             logits, raw = self.engine.outputs_btn()
             nc = torch.argmax(logits[:, -1], dim=-1)                 # (B,N), as trainer.py:467
             nb = torch.sigmoid(raw[:, -1])
