@@ -146,7 +146,10 @@ int vlg_linear_wgrad(const void* dY, int ldy, const void* X, int ldx,
  * storage: two launches).  Replaces the two autograd nodes of one nn.Linear backward. */
 int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, int ldw, void* dX, int ldx, const void* aux_in,
                            const void* X, int ldxx, float* slabs, int64_t slab_stride, int64_t slab_capacity,
-                           int64_t M, int N, int K, int epilogue, void* stream);
+                           int64_t M, int N, int K, int epilogue,
+                           const int64_t* rider_table /* NULL, or a vlg_reduce_slabs_table table over OTHER buffers (a finished
+                              gradient bucket's partial sums): reduced by extra blocks of the same launch where the products are
+                              fused, by its own launch otherwise */, int rider_rows, void* stream);
 
 
 /* ------------------------------------------------------------------- attention

@@ -271,7 +271,7 @@ def test_linear_dgrad_wgrad_is_the_two_calls(H, dev, M, N, K, mul):
         dx = torch.full((M, K), float("nan"), device=dev)
         if fused:
             H.call("vlg_linear_dgrad_wgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, H.ptr(auxd), xd.data_ptr(), K,
-                   slabs.data_ptr(), L, slabs.numel(), M, N, K, epi, stream())
+                   slabs.data_ptr(), L, slabs.numel(), M, N, K, epi, 0, 0, stream())
         else:
             H.call("vlg_linear_wgrad", dyd.data_ptr(), N, xd.data_ptr(), K, slabs.data_ptr(), L, slabs.numel(), M, N, K, 0, stream())
             H.call("vlg_linear_dgrad", dyd.data_ptr(), N, wd.data_ptr(), K, dx.data_ptr(), K, H.ptr(auxd), M, N, K, epi, stream())
@@ -307,7 +307,7 @@ def test_linear_dgrad_wgrad_bf16_storage_is_the_two_calls(H, dev, M, N, K, mul, 
         dx = torch.full((M, K), float("nan"), device=dev, dtype=bf)
         if fused:
             H.call("vlg_linear_dgrad_wgrad", dy.data_ptr(), N, w.data_ptr(), K, dx.data_ptr(), K, H.ptr(aux), x.data_ptr(), K,
-                   slabs.data_ptr(), L, slabs.numel(), M, N, K, epi | FL | H.EPI_OUT_BF16, stream())
+                   slabs.data_ptr(), L, slabs.numel(), M, N, K, epi | FL | H.EPI_OUT_BF16, 0, 0, stream())
         else:
             H.call("vlg_linear_wgrad", dy.data_ptr(), N, x.data_ptr(), K, slabs.data_ptr(), L, slabs.numel(), M, N, K, FL, stream())
             H.call("vlg_linear_dgrad", dy.data_ptr(), N, w.data_ptr(), K, dx.data_ptr(), K, H.ptr(aux), M, N, K, epi | FL | H.EPI_OUT_BF16, stream())

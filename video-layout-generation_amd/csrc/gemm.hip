@@ -39,6 +39,7 @@
 #include <stdlib.h>
 
 #include "gemm_tile.h"
+#include "reduce_body.h"
 
 // keeps the hand-placed order "next chunk's LDS reads, then this chunk's MFMAs" (see ldfrag below); VLG_NO_SCHED_FENCE
 // builds the loop without it (A/B switch for tools/kernel_bench.py)
@@ -655,15 +656,23 @@ __global__ __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (BM == 64 && 
 // of its own launch (same tiles, same split plan, same sums: bit for bit the two launches), but the chip is dealt both at
 // once: launches that cannot fill 256 CUs on their own (few tokens per GPU: the strong-scaling shard) share it, and one
 // launch ramp / drain is paid instead of two.
+// Blocks past both problems are RIDERS: rows of a slab-reduction table (the previous gradient bucket's partial sums, complete
+// since the launches that wrote them precede this one on the stream; this launch's weight gradient writes the OTHER arena).
+// The reduction is pure bandwidth work on 256-thread blocks that need 4 KB of LDS: it runs in the slots the GEMM blocks leave
+// towards the end of the launch instead of as a launch of its own.
 template <int BT, int EPI_D>
-__global__ __launch_bounds__(GEMM_THREADS, BT == 64 ? 4 : 2) void gemm_pair_kernel(const GemmArgs gd, const GemmArgs gw, const int nd, const int nd_pad) {
+__global__ __launch_bounds__(GEMM_THREADS, BT == 64 ? 4 : 2) void gemm_pair_kernel(const GemmArgs gd, const GemmArgs gw, const int nd, const int nd_pad,
+                                                                                   const int nw, const int64_t* __restrict__ rider, const int rider_bpr) {
     constexpr int FD = gemm_smem_floats<BT, BT, 32, true, false>(), FW = gemm_smem_floats<BT, BT, 32, false, false>();
     __shared__ __attribute__((aligned(16))) float smem_all[FD > FW ? FD : FW];
     const int b = (int)blockIdx.x;
     if (b < nd_pad) {
         if (b < nd) gemm_f32_body<BT, BT, 32, true, false, EPI_D, false>(gd, smem_all, b, nd);
+    } else if (b < nd_pad + nw) {
+        gemm_f32_body<BT, BT, 32, false, false, VLG_EPI_NONE, true>(gw, smem_all, b - nd_pad, nw);
     } else {
-        gemm_f32_body<BT, BT, 32, false, false, VLG_EPI_NONE, true>(gw, smem_all, b - nd_pad, (int)gridDim.x - nd_pad);
+        const int rb = b - nd_pad - nw;
+        reduce_table_row(rider, rb / rider_bpr, rb % rider_bpr, rider_bpr, reinterpret_cast<float4(*)[16]>(smem_all));
     }
 }
 
@@ -987,23 +996,33 @@ static int gemm_pair_mode() {
     static const int mode = [] { const char* e = getenv("VLG_GEMM_PAIR"); return e ? atoi(e) : 2; }();
     return mode;
 }
+#define VLG_RIDER_BPR 128          /* blocks per table row: what vlg_reduce_slabs_table launches get from the engine */
 template <int BT, int EPI_D>
-static int launch_pair(GemmArgs gd, GemmArgs gw, hipStream_t s) {
+static int launch_pair(GemmArgs gd, GemmArgs gw, const int64_t* rider, int rider_rows, hipStream_t s) {
     gd.tiles_m = (int)((gd.M + BT - 1) / BT); gd.tiles_n = (gd.N + BT - 1) / BT; gd.run = 1; gd.clock_probe = nullptr;
     gw.tiles_m = (int)((gw.M + BT - 1) / BT); gw.tiles_n = (gw.N + BT - 1) / BT; gw.run = 1; gw.clock_probe = nullptr;
     if constexpr (BT == 128) gd.run = gemm_run<128, 128, 32, true, false>(gd, 512);
     const int64_t nd = (int64_t)gd.tiles_m * (gd.tiles_n / gd.run), nw = (int64_t)gw.tiles_m * gw.tiles_n * gw.splits;
     const int64_t nd_pad = (nd + 7) / 8 * 8;
-    if (nd < 1 || nw < 1 || nd_pad + nw > 0x7fffffff) return VLG_ERR_SHAPE;
-    hipLaunchKernelGGL((gemm_pair_kernel<BT, EPI_D>), dim3((unsigned)(nd_pad + nw)), dim3(GEMM_THREADS), 0, s, gd, gw, (int)nd, (int)nd_pad);
+    const int64_t nr = rider ? (int64_t)rider_rows * VLG_RIDER_BPR : 0;
+    if (nd < 1 || nw < 1 || nd_pad + nw + nr > 0x7fffffff) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL((gemm_pair_kernel<BT, EPI_D>), dim3((unsigned)(nd_pad + nw + nr)), dim3(GEMM_THREADS), 0, s, gd, gw, (int)nd, (int)nd_pad,
+                       (int)nw, rider, VLG_RIDER_BPR);
     return vlg_last_error();
 }
 
+extern "C" int vlg_reduce_slabs_table(const int64_t* table, int n_rows, int blocks_per_row, void* stream);
+
 extern "C" int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, int ldw, void* dX, int ldx, const void* aux_in,
                                       const void* X, int ldxx, float* slabs, int64_t slab_stride, int64_t slab_capacity,
-                                      int64_t M, int N, int K, int epilogue, void* stream) {
+                                      int64_t M, int N, int K, int epilogue, const int64_t* rider_table, int rider_rows,
+                                      void* stream) {
     // dX[M,K] = dY[M,N] . W[N,K] (x aux_in with VLG_EPI_MUL)   and   slab[s] = dY^T . X, column sums of dY  - the results of
-    // vlg_linear_wgrad followed by vlg_linear_dgrad with the same arguments, bit for bit
+    // vlg_linear_wgrad followed by vlg_linear_dgrad with the same arguments, bit for bit.  rider_table (may be NULL): rows of
+    // a slab-reduction table (vlg_reduce_slabs_table) over OTHER buffers than this call writes, reduced by extra blocks of the
+    // same launch where the two products are fused, by a launch of their own otherwise - same sums either way.
+    if (rider_table != nullptr && (rider_rows < 1 || rider_rows > 4096)) return VLG_ERR_SHAPE;
+    auto rider_alone = [&]() -> int { return rider_table ? vlg_reduce_slabs_table(rider_table, rider_rows, VLG_RIDER_BPR, stream) : 0; };
     // the bf16-storage step (bf16 W / X / dX, dY bf16 or fp32): one launch of the bf16-tile kernels at every shape
     const int st_bits = epilogue & (VLG_EPI_A_BF16 | VLG_EPI_B_BF16 | VLG_EPI_OUT_BF16);
     if ((epilogue & VLG_EPI_BF16) && (st_bits & ~VLG_EPI_A_BF16) == (VLG_EPI_B_BF16 | VLG_EPI_OUT_BF16) && gemm_pair_mode() > 1 && N > 32 && K > 32) {
@@ -1023,6 +1042,7 @@ extern "C" int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, in
         wgrad_plan(M, N, K, &gw.splits, &gw.kc_per_split, true);
         if (slab_stride < (int64_t)N * K + N || slab_capacity < (int64_t)gw.splits * slab_stride) return VLG_ERR_SHAPE;
         gw.slab_stride = slab_stride; gw.colsum_off = (int64_t)N * K;
+        if (const int rc = rider_alone()) return rc;
         return vlg_gemm16_pair(gd, gw, epi, a16, (hipStream_t)stream);
     }
     const bool native = (epilogue & ~VLG_EPI_MUL) == 0;
@@ -1034,6 +1054,7 @@ extern "C" int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, in
     if (!pair) {
         // (bf16 storage: A = the shared dY, B = W of the data gradient AND X of the weight gradient, OUT = dX)
         const int wflags = epilogue & (VLG_EPI_BF16 | VLG_EPI_SPLIT3 | VLG_EPI_A_BF16 | VLG_EPI_B_BF16);
+        if (const int rc0 = rider_alone()) return rc0;
         const int rc = vlg_linear_wgrad(dY, ldy, X, ldxx, slabs, slab_stride, slab_capacity, M, N, K, wflags, stream);
         if (rc != 0) return rc;
         return vlg_linear_dgrad(dY, ldy, W, ldw, dX, ldx, aux_in, M, N, K, epilogue, stream);
@@ -1051,6 +1072,6 @@ extern "C" int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, in
     gw.splits = splits; gw.kc_per_split = per; gw.slab_stride = slab_stride; gw.colsum_off = (int64_t)N * K;
     hipStream_t s = (hipStream_t)stream;
     const bool mul = (epilogue & VLG_EPI_MUL) != 0;
-    if (small_d) return mul ? launch_pair<64, VLG_EPI_MUL>(gd, gw, s) : launch_pair<64, VLG_EPI_NONE>(gd, gw, s);
-    return mul ? launch_pair<128, VLG_EPI_MUL>(gd, gw, s) : launch_pair<128, VLG_EPI_NONE>(gd, gw, s);
+    if (small_d) return mul ? launch_pair<64, VLG_EPI_MUL>(gd, gw, rider_table, rider_rows, s) : launch_pair<64, VLG_EPI_NONE>(gd, gw, rider_table, rider_rows, s);
+    return mul ? launch_pair<128, VLG_EPI_MUL>(gd, gw, rider_table, rider_rows, s) : launch_pair<128, VLG_EPI_NONE>(gd, gw, rider_table, rider_rows, s);
 }

@@ -231,10 +231,15 @@ class LayoutEngine:
             pad = lambda v: (v + 3) // 4 * 4
             layer = sum(pad(v) for v in need[2:6]) + 2 * pad(need[1])
             head = pad(need[6]) + pad(need[1])
-            self.garena = torch.empty(max(layer, head, pad(need[0])), **f32)
+            # TWO arenas: a finished bucket's table may be reduced by rider blocks of the NEXT paired launch (which writes its
+            # own partial sums into the other arena) instead of by a launch of its own - _join_reduces(defer=True)
+            self.garenas = [torch.empty(max(layer, head, pad(need[0])), **f32) for _ in range(2)]
+            self._gsel = 0
             self._goff = 0
             self._grows: list = []
             self._gtables: Dict[tuple, torch.Tensor] = {}
+            self._pending = None                     # (table rows, callback) of a bucket waiting for its ride
+            self.ride_reduces = (self.pair_backward and self.precision == "fp32" and os.environ.get("VLG_RIDE_REDUCE", "1") == "1")
         else:   # one arena per producer family, each reduced right behind its producer (before the next one writes)
             self.slabs = torch.empty(max(need[:2]), **f32)          # layer-norm, embedding (main stream)
             self.slabs_w = torch.empty(max(need[2:]), **f32)        # weight gradients (the side stream in a two-stream backward)
@@ -249,12 +254,13 @@ class LayoutEngine:
         bucket's arena.  Otherwise one arena per producer family ("w": weight gradients, "s": layer-norm / embedding), whose
         previous contents were reduced on the same stream right behind their producer."""
         if self.group_reduce:
+            garena = self.garenas[self._gsel]
             off = self._goff
-            if off + need > self.garena.numel():
-                raise RuntimeError("partial-sum arena of %d floats is too small for %d more" % (self.garena.numel(), need))
+            if off + need > garena.numel():
+                raise RuntimeError("partial-sum arena of %d floats is too small for %d more" % (garena.numel(), need))
             self._goff = off + (need + 3) // 4 * 4
-            self._gcur = self.garena.data_ptr() + 4 * off
-            return self.garena[off:off + need]
+            self._gcur = garena.data_ptr() + 4 * off
+            return garena[off:off + need]
         return self.slabs_w if kind == "w" else self.slabs
 
     def _reduce(self, kind: str, stride: int, n_slabs: int, dst_off: int, dst_len: int) -> None:
@@ -266,20 +272,46 @@ class LayoutEngine:
             return
         call("vlg_reduce_slabs", ptr(self.slabs_w if kind == "w" else self.slabs), stride, n_slabs, dst, dst_len, self._stream())
 
-    def _join_reduces(self) -> None:
-        """grouped reductions: the one launch of the bucket that is complete now, on the current stream (a table of
-        {slabs, stride, count, destination, length} rows in device memory, built once per batch geometry)"""
+    def _table(self, rows: tuple) -> torch.Tensor:
+        table = self._gtables.get(rows)
+        if table is None:
+            table = torch.tensor([v for row in rows for v in row], dtype=torch.int64, device=self.device)
+            self._gtables[rows] = table
+        return table
+
+    def _join_reduces(self, defer: bool = False, then=None) -> None:
+        """grouped reductions: the bucket that is complete now (a table of {slabs, stride, count, destination, length} rows in
+        device memory, built once per batch geometry) is reduced by ONE launch on the current stream - or, with defer=True
+        and a paired launch to follow, handed to that launch as rider blocks (vlg_linear_dgrad_wgrad: the next producers then
+        write the other arena).  `then` (e.g. reducer.ready of the bucket) runs once the reduction has been enqueued.  A
+        bucket still waiting when another one completes travels in the same table."""
         if not self.group_reduce:
+            if then is not None:
+                then()
             return
-        if self._grows:
-            key = tuple(self._grows)
-            table = self._gtables.get(key)
-            if table is None:
-                table = torch.tensor([v for row in key for v in row], dtype=torch.int64, device=self.device)
-                self._gtables[key] = table
-            call("vlg_reduce_slabs_table", ptr(table), len(key), 128, self._stream())
-            self._grows = []
+        rows = tuple(self._grows)
+        self._grows = []
         self._goff = 0
+        if defer and self.ride_reduces and rows and self._pending is None:
+            self._pending = (rows, then)
+            self._gsel ^= 1
+            return
+        waiting, self._pending = self._pending, None
+        if waiting is not None:
+            rows = waiting[0] + rows
+        if rows:
+            call("vlg_reduce_slabs_table", ptr(self._table(rows)), len(rows), 128, self._stream())
+        if waiting is not None and waiting[1] is not None:
+            waiting[1]()
+        if then is not None:
+            then()
+
+    def _take_rider(self):
+        """(table pointer, rows, callback) of the bucket waiting for a ride, for the paired launch about to be enqueued"""
+        if not self.group_reduce or self._pending is None:
+            return 0, 0, None
+        (rows, then), self._pending = self._pending, None
+        return ptr(self._table(rows)), len(rows), then
 
     def _timed(self, family: str, flops: float, name: str, *args, nbytes: float = 0.0) -> None:
         """Launch through the C ABI; when a timer is attached, bracket the launch with events on
@@ -337,8 +369,12 @@ class LayoutEngine:
         bits = self._storage_bits(dy, w, dx)       # bf16 mode: A = the shared dY, B = W (data gradient) AND X (weight gradient), OUT = dX
         if (x.dtype == torch.bfloat16) != (w.dtype == torch.bfloat16):
             raise ValueError("paired backward: X and W must have the same storage type")
+        rider, rider_rows, then = self._take_rider()       # a finished bucket's reduction rides in this launch
         self._timed("gemm_pair", 4.0 * M * N * K, "vlg_linear_dgrad_wgrad", ptr(dy), N, ptr(w), K, ptr(dx), K, ptr(aux_in),
-                    ptr(x), K, ptr(arena), stride, arena.numel(), M, N, K, epi | self.gemm_flags | bits, self._stream(), nbytes=nb)
+                    ptr(x), K, ptr(arena), stride, arena.numel(), M, N, K, epi | self.gemm_flags | bits, rider, rider_rows,
+                    self._stream(), nbytes=nb)
+        if then is not None:
+            then()
         self._reduce("w", stride, n_slabs, self.layout[wname][0], stride)
 
     def _attn_fwd(self, l: int, batch, B, T, N, M) -> None:
@@ -484,21 +520,24 @@ class LayoutEngine:
                 main.wait_event(e)
                 last_read.clear()
 
+        if self.group_reduce:
+            self._gsel = 0          # every step uses the arenas in the same order: the reduction tables (device memory, cached by
+                                    # their rows) are the same from step to step - also what a captured hipGraph needs
         on_side(("dout",), lambda: self._wgrad(self.dout, self.xf, "head_w", M, cfg.n_out, d))
         self._dgrad(self.dout, self.pw("head_w"), self.dh, M, cfg.n_out, d)
         self._ln_bwd(self.dh, self.x[L], self.stats[2 * L], "lnf_g", None, self.dx, M)
+        paired = self.pair_backward and self._pair_shapes(M)
+        ready = (lambda tag: (lambda: reducer.ready(tag))) if reducer is not None else (lambda tag: None)
         if reducer is not None or self.group_reduce:
             join()
-            self._join_reduces()
-        if reducer is not None:
-            reducer.ready("head")
+            self._join_reduces(defer=paired, then=ready("head"))      # (paired: rides in the last layer's first launch)
         if self.overlap_small and not self.overlap_wgrad:
             self._backward_layers_paired(B, T, N, M, reducer)
             self._backward_tail(batch, B, T, N, M, reducer)
             return
         for l in reversed(range(L)):
             pre = "l%d." % l
-            if self.pair_backward and self._pair_shapes(M):
+            if paired:
                 self._dgrad_wgrad(self.dx, self.pw(pre + "ff2_w"), self.du, self.gl[l], pre + "ff2_w", M, d, ff, self._epi_dff2, aux_in=self.u[l])
                 self._dgrad_wgrad(self.du, self.pw(pre + "ff1_w"), self.dh, self.h2[l], pre + "ff1_w", M, ff, d)
                 self._ln_bwd(self.dh, self.xmid[l], self.stats[2 * l + 1], pre + "ln2_g", self.dx, self.dx, M)
@@ -506,9 +545,8 @@ class LayoutEngine:
                 self._attn_bwd(l, batch, B, T, N, M)
                 self._dgrad_wgrad(self.dqkv, self.pw(pre + "qkv_w"), self.dh, self.h1[l], pre + "qkv_w", M, 3 * d, d)
                 self._ln_bwd(self.dh, self.x[l], self.stats[2 * l], pre + "ln1_g", self.dx, self.dx, M)
-                self._join_reduces()
-                if reducer is not None:
-                    reducer.ready("l%d" % l)
+                # the layer's bucket rides in the next layer's first paired launch (layer 0: in the embedding bucket's table)
+                self._join_reduces(defer=True, then=ready("l%d" % l))
                 continue
             # FFN:  x_out = xmid + W2 gelu(W1 h2 + b1) + b2
             if self.gelu_on_load:
@@ -555,9 +593,8 @@ class LayoutEngine:
         self._timed("embed_bwd", 0.0, "vlg_embed_bwd", ptr(self.dx), ptr(batch["slot_class"]), ptr(batch["slot_box"]), ptr(arena),
                     emb_len, arena.numel(), B, T, N, d, cfg.vocab, s, nbytes=4.0 * M * d + 24.0 * M)
         self._reduce("s", emb_len, n_slabs, 0, emb_len)
-        self._join_reduces()                       # the gradient buffer is complete for whoever runs next on this stream
-        if reducer is not None:
-            reducer.ready("embed")
+        # (flushes a bucket still waiting for a ride in the same table: the gradient buffer is complete for whoever runs next)
+        self._join_reduces(then=(lambda: reducer.ready("embed")) if reducer is not None else None)
 
     def _backward_layers_paired(self, B, T, N, M, reducer) -> None:
         """Backward of the layers with every bandwidth-bound kernel of the chain launched on the side stream BESIDE the

@@ -37,7 +37,7 @@ SIGNATURES = {
     "vlg_linear_fwd": (I, [P, I, P, I, P, P, I, P, P, L, I, I, I, P]),
     "vlg_linear_dgrad": (I, [P, I, P, I, P, I, P, L, I, I, I, P]),
     "vlg_linear_wgrad_slabs": (I, [L, I, I]),
-    "vlg_linear_dgrad_wgrad": (I, [P, I, P, I, P, I, P, P, I, P, L, L, L, I, I, I, P]),
+    "vlg_linear_dgrad_wgrad": (I, [P, I, P, I, P, I, P, P, I, P, L, L, L, I, I, I, P, I, P]),
     "vlg_linear_wgrad_slabs_for": (I, [L, I, I, I]),
     "vlg_linear_wgrad": (I, [P, I, P, I, P, L, L, L, I, I, I, P]),
     "vlg_attention_fwd": (I, [P, P, L, I, I, P]),
