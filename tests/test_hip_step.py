@@ -297,12 +297,14 @@ def test_captured_step_replays_bitwise(dev, precision):
         assert torch.equal(graphed.params_bf16, graphed.params.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("option,value", [("VLG_OVERLAP_WGRAD", "1"), ("VLG_GROUP_REDUCE", "0"), ("VLG_OVERLAP_SMALL", "1")])
+@pytest.mark.parametrize("option,value", [("VLG_OVERLAP_WGRAD", "1"), ("VLG_GROUP_REDUCE", "0"), ("VLG_OVERLAP_SMALL", "1"),
+                                          ("VLG_RIDE_REDUCE", "0"), ("VLG_PAIR_BACKWARD", "0")])
 def test_stream_options_do_not_change_results(dev, option, value, monkeypatch):
     """The engine's launch-order options (weight gradients on a second stream, every partial-sum reduction as a launch of
     its own behind its producer instead of one table-driven launch per bucket, bandwidth-bound kernels beside the weight
-    gradients) only reorder or regroup launches: parameters and losses after three steps must be bit for bit those of
-    the default step."""
+    gradients; round 3: a bucket's reduction as a launch of its own instead of rider blocks of the next paired launch, a
+    projection's data gradient and weight gradient as two calls instead of one) only reorder or regroup launches:
+    parameters and losses after three steps must be bit for bit those of the default step."""
     from vlg.engine import LayoutEngine
     from vlg.spec import LayoutConfig
     cfg = LayoutConfig(B=4, T=16, N=24, d=256, n_layers=2)
@@ -312,8 +314,11 @@ def test_stream_options_do_not_change_results(dev, option, value, monkeypatch):
     monkeypatch.setenv(option, value)
     opt = LayoutEngine(cfg, dev)
     monkeypatch.delenv(option)
-    assert {"VLG_OVERLAP_WGRAD": opt.overlap_wgrad, "VLG_GROUP_REDUCE": not opt.group_reduce, "VLG_OVERLAP_SMALL": opt.overlap_small}[option]
-    assert not opt.group_reduce
+    assert plain.pair_backward and plain.ride_reduces
+    assert {"VLG_OVERLAP_WGRAD": opt.overlap_wgrad, "VLG_GROUP_REDUCE": not opt.group_reduce, "VLG_OVERLAP_SMALL": opt.overlap_small,
+            "VLG_RIDE_REDUCE": opt.pair_backward and not opt.ride_reduces, "VLG_PAIR_BACKWARD": not opt.pair_backward}[option]
+    if option in ("VLG_OVERLAP_WGRAD", "VLG_GROUP_REDUCE", "VLG_OVERLAP_SMALL"):
+        assert not opt.group_reduce
     for b in batches:
         lp = plain.train_step(b).clone()
         lo = opt.train_step(b).clone()

@@ -227,6 +227,7 @@ class LayoutEngine:
         # stream; the library decides per shape (VLG_GEMM_PAIR)
         self.pair_backward = (not self.overlap_wgrad and not self.overlap_small and not self.gelu_on_load
                               and self.precision in ("fp32", "bf16") and os.environ.get("VLG_PAIR_BACKWARD", "1") == "1")
+        self.ride_reduces = False
         if self.group_reduce:
             pad = lambda v: (v + 3) // 4 * 4
             layer = sum(pad(v) for v in need[2:6]) + 2 * pad(need[1])
