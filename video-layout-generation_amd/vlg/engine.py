@@ -310,8 +310,10 @@ class LayoutEngine:
     def _take_rider(self):
         """(table pointer, rows, callback) of the bucket waiting for a ride, for the paired launch about to be enqueued"""
         if not self.group_reduce or self._pending is None:
+            self._rider_bytes = 0.0
             return 0, 0, None
         (rows, then), self._pending = self._pending, None
+        self._rider_bytes = 4.0 * sum((n_slabs + 1) * length for (_, _, n_slabs, _, length) in rows)   # slabs read + sums written
         return ptr(self._table(rows)), len(rows), then
 
     def _timed(self, family: str, flops: float, name: str, *args, nbytes: float = 0.0) -> None:
@@ -370,10 +372,10 @@ class LayoutEngine:
         bits = self._storage_bits(dy, w, dx)       # bf16 mode: A = the shared dY, B = W (data gradient) AND X (weight gradient), OUT = dX
         if (x.dtype == torch.bfloat16) != (w.dtype == torch.bfloat16):
             raise ValueError("paired backward: X and W must have the same storage type")
-        rider, rider_rows, then = self._take_rider()       # a finished bucket's reduction rides in this launch
+        rider, rider_rows, then = self._take_rider()       # a finished bucket's reduction rides in this launch (its bytes count)
         self._timed("gemm_pair", 4.0 * M * N * K, "vlg_linear_dgrad_wgrad", ptr(dy), N, ptr(w), K, ptr(dx), K, ptr(aux_in),
                     ptr(x), K, ptr(arena), stride, arena.numel(), M, N, K, epi | self.gemm_flags | bits, rider, rider_rows,
-                    self._stream(), nbytes=nb)
+                    self._stream(), nbytes=nb + self._rider_bytes)
         if then is not None:
             then()
         self._reduce("w", stride, n_slabs, self.layout[wname][0], stride)
