@@ -821,7 +821,7 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
 int vlg_gemm16_fwd(GemmArgs g, int epilogue, int io, hipStream_t s);
 int vlg_gemm16_dgrad(GemmArgs g, int epilogue, int io, hipStream_t s);
 int vlg_gemm16_wgrad(GemmArgs g, int io, hipStream_t s);
-int vlg_gemm16_pair(GemmArgs gd, GemmArgs gw, int epilogue, bool dy_bf16, hipStream_t s);
+int vlg_gemm16_pair(GemmArgs gd, GemmArgs gw, int epilogue, bool dy_bf16, const int64_t* rider, int rider_rows, int rider_bpr, hipStream_t s);
 // fp32 operands split into three bf16 terms, six bf16 MFMAs per product block (gemm_split.hip)
 int vlg_gemm_split_fwd(GemmArgs g, int epilogue, hipStream_t s);
 int vlg_gemm_split_dgrad(GemmArgs g, int epilogue, hipStream_t s);
@@ -1042,8 +1042,7 @@ extern "C" int vlg_linear_dgrad_wgrad(const void* dY, int ldy, const void* W, in
         wgrad_plan(M, N, K, &gw.splits, &gw.kc_per_split, true);
         if (slab_stride < (int64_t)N * K + N || slab_capacity < (int64_t)gw.splits * slab_stride) return VLG_ERR_SHAPE;
         gw.slab_stride = slab_stride; gw.colsum_off = (int64_t)N * K;
-        if (const int rc = rider_alone()) return rc;
-        return vlg_gemm16_pair(gd, gw, epi, a16, (hipStream_t)stream);
+        return vlg_gemm16_pair(gd, gw, epi, a16, rider_table, rider_rows, VLG_RIDER_BPR, (hipStream_t)stream);
     }
     const bool native = (epilogue & ~VLG_EPI_MUL) == 0;
     bool small_w = false;

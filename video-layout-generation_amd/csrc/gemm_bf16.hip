@@ -20,6 +20,7 @@
 #include "common.h"
 #include <type_traits>
 #include "gemm_tile16.h"
+#include "reduce_body.h"
 #include <stdlib.h>
 
 // LDS elements (bf16) of one block: both operand tiles, double-buffered
@@ -232,33 +233,42 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
 // A projection's data gradient (blocks [0, nd_pad): nd real, padded to a multiple of 8 for the XCD mapping of the second
 // problem) and weight gradient (the rest) in ONE launch - csrc/gemm.hip, gemm_pair_kernel.  The bf16-storage step's
 // combinations: dY bf16 or fp32 (A16), W / X bf16, dX (+ the multiply epilogue's operand) bf16.
+// (blocks past both problems: rider rows of a slab-reduction table, as in gemm_pair_kernel)
 template <int EPI_D, bool A16>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm16_pair_kernel(const GemmArgs gd, const GemmArgs gw, const int nd, const int nd_pad) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm16_pair_kernel(const GemmArgs gd, const GemmArgs gw, const int nd, const int nd_pad,
+                                                                     const int nw, const int64_t* __restrict__ rider, const int rider_bpr) {
     using EA = std::conditional_t<A16, bf16_t, float>;
     constexpr int FD = gemm16_smem_elems<128, 128, 64, true, false>(), FW = gemm16_smem_elems<128, 128, 64, false, false>();
     __shared__ __attribute__((aligned(16))) bf16_t smem[FD > FW ? FD : FW];
     const int b = (int)blockIdx.x;
     if (b < nd_pad) {
         if (b < nd) gemm16_body<128, 128, 64, true, false, EPI_D, false, EA, bf16_t, bf16_t>(gd, smem, b, nd);
+    } else if (b < nd_pad + nw) {
+        gemm16_body<128, 128, 64, false, false, VLG_EPI_NONE, true, EA, bf16_t, float>(gw, smem, b - nd_pad, nw);
     } else {
-        gemm16_body<128, 128, 64, false, false, VLG_EPI_NONE, true, EA, bf16_t, float>(gw, smem, b - nd_pad, (int)gridDim.x - nd_pad);
+        const int rb = b - nd_pad - nw;
+        reduce_table_row(rider, rb / rider_bpr, rb % rider_bpr, rider_bpr, reinterpret_cast<float4(*)[16]>(smem));
     }
 }
 template <int EPI_D, bool A16>
-static int launch16_pair(GemmArgs gd, GemmArgs gw, hipStream_t s) {
+static int launch16_pair(GemmArgs gd, GemmArgs gw, const int64_t* rider, int rider_rows, int rider_bpr, hipStream_t s) {
     gd.tiles_m = (int)((gd.M + 127) / 128); gd.tiles_n = (gd.N + 127) / 128; gd.clock_probe = nullptr; gd.run = 1;
     gw.tiles_m = (int)((gw.M + 127) / 128); gw.tiles_n = (gw.N + 127) / 128; gw.clock_probe = nullptr; gw.run = 1;
     const int64_t nd = (int64_t)gd.tiles_m * gd.tiles_n, nw = (int64_t)gw.tiles_m * gw.tiles_n * gw.splits;
     const int64_t nd_pad = (nd + 7) / 8 * 8;
-    if (nd < 1 || nw < 1 || nd_pad + nw > 0x7fffffff) return VLG_ERR_SHAPE;
-    hipLaunchKernelGGL((gemm16_pair_kernel<EPI_D, A16>), dim3((unsigned)(nd_pad + nw)), dim3(GEMM_THREADS), 0, s, gd, gw, (int)nd, (int)nd_pad);
+    const int64_t nr = rider ? (int64_t)rider_rows * rider_bpr : 0;
+    if (nd < 1 || nw < 1 || nd_pad + nw + nr > 0x7fffffff) return VLG_ERR_SHAPE;
+    hipLaunchKernelGGL((gemm16_pair_kernel<EPI_D, A16>), dim3((unsigned)(nd_pad + nw + nr)), dim3(GEMM_THREADS), 0, s, gd, gw, (int)nd, (int)nd_pad,
+                       (int)nw, rider, rider_bpr);
     return vlg_last_error();
 }
 // bf16-storage pair (W / X / dX bf16): dy_bf16 = the shared dY is bf16 (else fp32: a residual-stream gradient)
-int vlg_gemm16_pair(GemmArgs gd, GemmArgs gw, int epilogue, bool dy_bf16, hipStream_t s) {
+int vlg_gemm16_pair(GemmArgs gd, GemmArgs gw, int epilogue, bool dy_bf16, const int64_t* rider, int rider_rows, int rider_bpr, hipStream_t s) {
     if ((gd.ldc & 7) || !vlg_aligned16(gd.C) || (gd.Kc & 7) || (gd.N & 7) || (gw.M & 7) || (gw.N & 7) || gw.M <= 32) return VLG_ERR_SHAPE;
-    if (epilogue == VLG_EPI_NONE) return dy_bf16 ? launch16_pair<VLG_EPI_NONE, true>(gd, gw, s) : launch16_pair<VLG_EPI_NONE, false>(gd, gw, s);
-    if (epilogue == VLG_EPI_MUL) return dy_bf16 ? launch16_pair<VLG_EPI_MUL, true>(gd, gw, s) : launch16_pair<VLG_EPI_MUL, false>(gd, gw, s);
+#define PAIR16(EPI, A16) launch16_pair<EPI, A16>(gd, gw, rider, rider_rows, rider_bpr, s)
+    if (epilogue == VLG_EPI_NONE) return dy_bf16 ? PAIR16(VLG_EPI_NONE, true) : PAIR16(VLG_EPI_NONE, false);
+    if (epilogue == VLG_EPI_MUL) return dy_bf16 ? PAIR16(VLG_EPI_MUL, true) : PAIR16(VLG_EPI_MUL, false);
+#undef PAIR16
     return VLG_ERR_SHAPE;
 }
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, int IO>

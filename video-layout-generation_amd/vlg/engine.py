@@ -240,7 +240,7 @@ class LayoutEngine:
             self._grows: list = []
             self._gtables: Dict[tuple, torch.Tensor] = {}
             self._pending = None                     # (table rows, callback) of a bucket waiting for its ride
-            self.ride_reduces = (self.pair_backward and self.precision == "fp32" and os.environ.get("VLG_RIDE_REDUCE", "1") == "1")
+            self.ride_reduces = self.pair_backward and os.environ.get("VLG_RIDE_REDUCE", "1") == "1"
         else:   # one arena per producer family, each reduced right behind its producer (before the next one writes)
             self.slabs = torch.empty(max(need[:2]), **f32)          # layer-norm, embedding (main stream)
             self.slabs_w = torch.empty(max(need[2:]), **f32)        # weight gradients (the side stream in a two-stream backward)
