@@ -78,25 +78,8 @@ __device__ __forceinline__ void stage_transposed(float* Xt, int tok, int c4, con
     p += 32 * CLDT;
     p[0] = v.b.x; p[CLDT] = v.b.y; p[2 * CLDT] = v.b.z; p[3 * CLDT] = v.b.w;
 }
-// fragment of the row-major tile for MFMA step i of lane (l31, h): X[l31][32 h + i], i = 0 .. 31
-__device__ __forceinline__ void frag_rows(float (&f)[32], const float* Xs, int l31, int h) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float4 t = ld4(Xs + l31 * CLDR + 32 * h + 4 * c);
-        f[4 * c] = t.x; f[4 * c + 1] = t.y; f[4 * c + 2] = t.z; f[4 * c + 3] = t.w;
-    }
-}
-// D[row][col] = sum over the 64 dims of A[row][dim] B[col][dim]: a = A fragment, b = B fragment (both "X[l31][32h + i]")
-__device__ __forceinline__ f32x16 dot64(const float (&a)[32], const float (&b)[32]) {
-    f32x16 c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) c = MFMA32(a[i], b[i], c);
-    return c;
-}
-// the same with the A fragment read from the row-major LDS tile as it is consumed (four values per ds_read_b128: the
-// fragment never occupies 32 registers at once)
+// D[row][col] = sum over the 64 dims of A[row][dim] B[col][dim], both operands as "X[l31][32 h + i]", i = 0 .. 31 (MFMA step i of
+// lane (l31, h)): B = a register fragment, A = read from the row-major LDS tile as it is consumed (four values per ds_read_b128)
 __device__ __forceinline__ f32x16 dot64_rows(const float* Xs, int l31, int h, const float (&b)[32]) {
     f32x16 c;
 #pragma unroll

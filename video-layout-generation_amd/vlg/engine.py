@@ -383,7 +383,6 @@ class LayoutEngine:
     def _attn_fwd(self, l: int, batch, B, T, N, M) -> None:
         d, s = self.cfg.d, self._stream()
         if self.cfg.attention == "clip":
-            S2 = T * N
             fl = 4.0 * B * d * N * N * T * (T + 1) / 2.0            # visible (query, key) pairs x 2 products x 2 x head dim, all heads
             self._timed("attn_clip_fwd", fl, "vlg_attention_clip_fwd", ptr(self.qkv[l]), ptr(batch["valid"]) if self.padded_slots else 0,
                         ptr(self.att[l]), ptr(self.lse[l]), B, T, N, d, s, nbytes=16.0 * M * d)
